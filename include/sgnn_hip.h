@@ -1,0 +1,153 @@
+/*
+ * sgnn_hip.h — C ABI of libsgnn_hip.so, the MI355X (gfx950) implementation of
+ * SGNN's sparse propagation path:
+ *
+ *     A_hat = D^-1/2 (A + I) D^-1/2            (adjacency build)
+ *     Y     = A_hat^K . X                      (repeated CSR SpMM)
+ *
+ * The reference (tavogus55/SGNN) is pure Python and has no FFI layer of its
+ * own; each entry point below names the reference code it replaces
+ * (paths relative to the reference tree).  The Python surfaces that the
+ * reference's callers see (`csr_to_sparse_Tensor`,
+ * `process_data_with_adjacency_high_order`, `SGConv`, `GCNConv`) live in
+ * sgnn_amd/ and call these functions through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer; the library never allocates or frees
+ *     device memory (scratch comes in through `workspace`);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and the
+ *     call returns without synchronising;
+ *   - return value 0 = success, negative = error; the message for the calling
+ *     thread's last error is returned by sgnn_last_error();
+ *   - indices in CSR are int32 (n and nnz must stay below 2^31), values fp32.
+ */
+#ifndef SGNN_HIP_H
+#define SGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGNN_OK                0
+#define SGNN_ERR_INVALID      -1   /* bad argument (null pointer, negative size, n >= 2^31 ...) */
+#define SGNN_ERR_WORKSPACE    -2   /* workspace too small */
+#define SGNN_ERR_HIP          -3   /* a HIP call failed; see sgnn_last_error() */
+#define SGNN_ERR_UNSUPPORTED  -4
+
+/* build flags */
+#define SGNN_STRIP_DIAG        1   /* drop (i,i) entries of the input first: model/SGNN.py:497-501 */
+#define SGNN_DROP_ZEROS        2   /* drop entries whose merged value is 0 (scipy's sparse subtraction does) */
+/* self-loop modes */
+#define SGNN_LOOPS_NONE        0
+#define SGNN_LOOPS_ADD         1   /* A + I, diagonal value += 1: utils.py:83-86 */
+#define SGNN_LOOPS_REMAINING   2   /* diagonal = existing weight, else 1: torch_geometric gcn_norm's
+                                      add_remaining_self_loops, reached from model/SGC.py:14, model/GCN.py:14,16 */
+
+/* Library version (major*10000 + minor*100 + patch).  No reference counterpart. */
+int sgnn_version(void);
+
+/* Message of the calling thread's most recent failure ("" if none).
+ * The reference raises Python exceptions; the host layer turns a negative
+ * return code plus this string into a RuntimeError. */
+const char* sgnn_last_error(void);
+
+/* Bytes of device scratch sgnn_build_norm_csr needs for an n x n matrix given
+ * as nnz_in COO entries. */
+size_t sgnn_build_workspace_bytes(int64_t n, int64_t nnz_in);
+
+/*
+ * COO (int64 row/col, fp32 val, duplicates allowed, any order) ->
+ * canonical CSR of the matrix the propagation multiplies by, its weighted row
+ * degree and dinv = 1/sqrt(deg).
+ *
+ * Replaces: utils.py:54-62 (scipy -> torch COO upload), utils.py:82-89
+ * (self-loop COO, A + I, torch.sparse.sum row degree, sqrt, reciprocal — all
+ * redone by the reference on every call) and, with SGNN_STRIP_DIAG,
+ * model/SGNN.py:497-501.
+ *
+ *   val        nullable: every entry has weight 1
+ *   rowptr     [n+1] int32 out
+ *   colidx     [nnz_in + n] int32 out (capacity; *nnz_out entries are valid)
+ *   vals       [nnz_in + n] fp32 out
+ *   deg        [n] fp32 out: row sums, accumulated in fp32 in column order
+ *   dinv       [n] fp32 out: 1.0f / sqrtf(deg) (two roundings, as utils.py:88-89);
+ *              with zero_inf != 0 an infinite result is replaced by 0 (gcn_norm)
+ *   nnz_out    device int64 out
+ * Duplicates are summed in fp32 in input order; columns are sorted inside a row.
+ */
+int sgnn_build_norm_csr(int64_t n, int64_t nnz_in,
+                        const int64_t* row, const int64_t* col, const float* val,
+                        int flags, int self_loops, int zero_inf,
+                        int32_t* rowptr, int32_t* colidx, float* vals,
+                        float* deg, float* dinv, int64_t* nnz_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Bytes of device scratch sgnn_csr_transpose needs. */
+size_t sgnn_transpose_workspace_bytes(int64_t n, int64_t nnz);
+
+/*
+ * CSR of the transpose of an n x n canonical CSR (columns sorted inside a row).
+ * Needed for the backward of GCNConv (A_hat^T . dY, model/GCN.py:14-16 under
+ * autograd) when the adjacency is not symmetric.
+ */
+int sgnn_csr_transpose(int64_t n, int64_t nnz,
+                       const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                       int32_t* t_rowptr, int32_t* t_colidx, float* t_vals,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* epilogue modes of sgnn_spmm_csr_f32 */
+#define SGNN_EPI_SCALE_ROW     0   /* Y_i = dinv_row[i] * s_i                      (utils.py:95) */
+#define SGNN_EPI_SCALE_ROW2    1   /* Y_i = (dinv_row[i] * s_i) * dinv_row[i]: utils.py:95 of one hop
+                                      followed by utils.py:93 of the next, same two roundings */
+
+/* Bytes of device scratch one sgnn_spmm_csr_f32 / sgnn_spmm_chain_f32 call needs
+ * (partial sums of rows that are split over several wavefronts). */
+size_t sgnn_spmm_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t F);
+
+/*
+ * Y[n_rows, F] = diag(dinv_row) . CSR . diag(dinv_col) . X      (fp32)
+ *
+ * Replaces one trip of the loop at utils.py:92-95 (row-scale, adj.mm,
+ * row-scale).  X has n_cols rows (n_cols = n_rows except for a row block of a
+ * partitioned matrix), nnz = rowptr[n_rows] (the host knows it; it sizes the
+ * scratch layout), leading dimensions ldx/ldy in elements.
+ *   vals      nullable: all stored entries are 1
+ *   dinv_col  nullable: X is already scaled (or no column scaling wanted)
+ *   dinv_row  nullable: no row scaling
+ * Each output row is reduced in an order that depends only on that row's
+ * entries, so results are reproducible run to run and identical for a row
+ * whichever row block it is computed in.  X and Y must not overlap.
+ */
+int sgnn_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F,
+                      const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                      const float* dinv_row, const float* dinv_col,
+                      const float* X, int64_t ldx, float* Y, int64_t ldy,
+                      int epilogue, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Y = A_hat^K . X for a square matrix: K hops of the kernel above with the
+ * normalisation between hops folded into the epilogue (SGNN_EPI_SCALE_ROW2), so
+ * no separate scaling pass touches the intermediates.  tmp is [n, F] fp32
+ * scratch (ld = F) and is used only when K > 1.
+ * Replaces utils.py:91-96 (whole loop) and the K x propagate of SGConv
+ * (model/SGC.py:11,14).
+ */
+int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
+                        const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                        const float* dinv,
+                        const float* X, int64_t ldx, float* Y, int64_t ldy, float* tmp,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i, 0:F] = scale[i] * in[i, 0:F]  — utils.py:93 as a stand-alone pass (used
+ * to pre-scale the row block a rank contributes to the all-gather). */
+int sgnn_row_scale_f32(int64_t n, int64_t F, const float* scale,
+                       const float* in, int64_t ldin, float* out, int64_t ldout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGNN_HIP_H */

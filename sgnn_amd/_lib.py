@@ -1,0 +1,81 @@
+"""ctypes binding of libsgnn_hip.so (declared in include/sgnn_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc,
+``--offload-arch=gfx950``).  There is no CPU fallback: if the shared object is
+missing or a GPU entry point is called without a GPU the caller gets an
+exception, never a silently slower path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgnn_hip.so")
+
+# constants of include/sgnn_hip.h
+STRIP_DIAG = 1
+DROP_ZEROS = 2
+LOOPS_NONE, LOOPS_ADD, LOOPS_REMAINING = 0, 1, 2
+EPI_SCALE_ROW, EPI_SCALE_ROW2 = 0, 1
+
+# name -> (restype, argtypes); every symbol the header declares
+SIGNATURES = {
+    "sgnn_version": (c_int, []),
+    "sgnn_last_error": (c_char_p, []),
+    "sgnn_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sgnn_build_norm_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    "sgnn_transpose_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sgnn_csr_transpose": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_size_t, c_void_p]),
+    "sgnn_spmm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "sgnn_spmm_csr_f32": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_size_t,
+                                  c_void_p]),
+    "sgnn_spmm_chain_f32": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class SgnnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgnnHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). sgnn_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().sgnn_last_error().decode("utf-8", "replace")
+        raise SgnnHipError(f"libsgnn_hip error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

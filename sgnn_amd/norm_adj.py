@@ -1,0 +1,240 @@
+"""``NormAdj`` — the device-resident form of the adjacency the propagation uses.
+
+The reference keeps the adjacency as a torch sparse COO tensor (int64 indices,
+fp32 values; utils.py:54-62) and, on EVERY call of
+``process_data_with_adjacency_high_order``, rebuilds ``A + I``, the row degree
+and ``1/sqrt(degree)`` from it (utils.py:82-89).  Here all of that is done once,
+on the GPU, into an int32 CSR plus ``deg``/``dinv`` vectors that stay in HBM;
+each later call is SpMM launches only.
+
+Layout in HBM (n nodes, nnz stored entries of A+I):
+  rowptr int32[n+1] | colidx int32[nnz] | vals fp32[nnz] | deg fp32[n] | dinv fp32[n]
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _as_index_tensor(a, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.int64).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int64))).to(device)
+
+
+def _require_gpu(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.SgnnHipError(
+            f"sgnn_amd runs on MI355X only (device={device}); there is no CPU path in this package")
+    if not torch.cuda.is_available():
+        raise _lib.SgnnHipError("no GPU visible to PyTorch-ROCm")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+class NormAdj:
+    """CSR of ``A (+ I)`` with degree vectors, resident on one GPU."""
+
+    def __init__(self, n, rowptr, colidx, vals, deg, dinv, unit_weights=False, symmetric=None):
+        self.n = int(n)
+        self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
+        self.deg, self.dinv = deg, dinv
+        self.nnz = int(colidx.numel())
+        self.unit_weights = bool(unit_weights)
+        self.device = rowptr.device
+        self._symmetric = symmetric
+        self._transposed = None
+        self._ws = {}
+
+    # the reference's callers only ever look at .shape[0] of the adjacency handle
+    # (model/SGNN.py:33)
+    @property
+    def shape(self):
+        return torch.Size((self.n, self.n))
+
+    def __repr__(self):
+        return f"NormAdj(n={self.n}, nnz={self.nnz}, device={self.device}, unit_weights={self.unit_weights})"
+
+    # ------------------------------------------------------------------ build
+    @classmethod
+    def from_coo(cls, row, col, val, n, device, strip_diag=False, self_loops=_lib.LOOPS_ADD,
+                 drop_zeros=False, zero_inf=False):
+        """Build from COO triples (duplicates summed; utils.py:54-62 + 82-89)."""
+        device = _require_gpu(device)
+        lib = _lib.load()
+        n = int(n)
+        if n <= 0:
+            raise ValueError("adjacency must have at least one node")
+        with torch.cuda.device(device):
+            row = _as_index_tensor(row, device)
+            col = _as_index_tensor(col, device)
+            if row.shape != col.shape or row.dim() != 1:
+                raise ValueError("row and col must be 1-D and of equal length")
+            nnz_in = int(row.numel())
+            if val is not None:
+                if not isinstance(val, torch.Tensor):
+                    val = torch.from_numpy(np.ascontiguousarray(np.asarray(val, dtype=np.float32)))
+                val = val.to(device=device, dtype=torch.float32).contiguous()
+                if val.numel() != nnz_in:
+                    raise ValueError("val must have one entry per (row, col) pair")
+            cap = nnz_in + n
+            rowptr = torch.empty(n + 1, dtype=torch.int32, device=device)
+            colidx = torch.empty(cap, dtype=torch.int32, device=device)
+            vals = torch.empty(cap, dtype=torch.float32, device=device)
+            deg = torch.empty(n, dtype=torch.float32, device=device)
+            dinv = torch.empty(n, dtype=torch.float32, device=device)
+            nnz_out = torch.zeros(1, dtype=torch.int64, device=device)
+            ws_bytes = lib.sgnn_build_workspace_bytes(n, nnz_in)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            flags = (_lib.STRIP_DIAG if strip_diag else 0) | (_lib.DROP_ZEROS if drop_zeros else 0)
+            _lib.check(lib.sgnn_build_norm_csr(
+                n, nnz_in, _lib.ptr(row), _lib.ptr(col), _lib.ptr(val), flags, int(self_loops),
+                1 if zero_inf else 0, _lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(vals), _lib.ptr(deg),
+                _lib.ptr(dinv), _lib.ptr(nnz_out), _lib.ptr(ws), ws_bytes, _lib.current_stream(device)))
+            total = int(nnz_out.item())          # synchronises the stream
+            del ws
+            if total < 0:
+                raise ValueError(f"adjacency indices out of range for a {n} x {n} matrix")
+            colidx = colidx[:total].clone()
+            vals = vals[:total].clone()
+            unit = bool((vals == 1.0).all().item()) if total else True
+        return cls(n, rowptr, colidx, vals, deg, dinv, unit_weights=unit)
+
+    @classmethod
+    def from_scipy(cls, mat, device, **kw):
+        """scipy sparse (any format) -> NormAdj; values cast to fp32 as utils.py:61 does."""
+        coo = mat.tocoo()
+        if coo.shape[0] != coo.shape[1]:
+            raise ValueError("adjacency must be square")
+        return cls.from_coo(coo.row, coo.col, np.asarray(coo.data, dtype=np.float32), coo.shape[0], device, **kw)
+
+    @classmethod
+    def from_torch_sparse(cls, t, device=None, **kw):
+        """torch sparse COO (as utils.py:59-62 builds it; need not be coalesced)."""
+        if t.layout != torch.sparse_coo:
+            raise ValueError("expected a torch sparse COO tensor")
+        if t.shape[0] != t.shape[1]:
+            raise ValueError("adjacency must be square")
+        idx = t._indices()
+        return cls.from_coo(idx[0], idx[1], t._values().to(torch.float32), t.shape[0],
+                            device if device is not None else t.device, **kw)
+
+    @classmethod
+    def from_edge_index(cls, edge_index, num_nodes, device=None, edge_weight=None, add_self_loops=True):
+        """PyG convention (model/SGC.py:14, model/GCN.py:14): messages flow
+        ``edge_index[0] -> edge_index[1]`` and the degree is the weighted in-degree
+        of the target.  As a matrix that is ``M[target, source]``, so targets are
+        the CSR rows here and the SGNN row-degree formula applies unchanged.
+        """
+        dev = device if device is not None else edge_index.device
+        return cls.from_coo(edge_index[1], edge_index[0], edge_weight, num_nodes, dev,
+                            self_loops=_lib.LOOPS_REMAINING if add_self_loops else _lib.LOOPS_NONE,
+                            zero_inf=True)
+
+    # --------------------------------------------------------------- plumbing
+    def _workspace(self, F):
+        ws = self._ws.get(F)
+        if ws is None:
+            nbytes = _lib.load().sgnn_spmm_workspace_bytes(self.n, self.nnz, F)
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self._ws = {F: ws}            # keep one: callers alternate between few widths
+        return ws
+
+    def _check_dense(self, X, rows):
+        if not isinstance(X, torch.Tensor) or X.dim() != 2:
+            raise ValueError("X must be a 2-D tensor")
+        if X.device != self.device:
+            raise ValueError(f"X is on {X.device}, adjacency on {self.device}")
+        if X.dtype != torch.float32:
+            raise ValueError("X must be float32")
+        if X.shape[0] != rows:
+            raise ValueError(f"X has {X.shape[0]} rows, adjacency expects {rows}")
+        if X.stride(1) != 1 or (X.shape[0] > 1 and X.stride(0) < X.shape[1]):
+            X = X.contiguous()
+        return X
+
+    # ------------------------------------------------------------------ apply
+    def spmm(self, X, scale_rows=True, scale_cols=True, epilogue=_lib.EPI_SCALE_ROW, out=None):
+        """One hop: ``diag(dinv) . (A+I) . diag(dinv) . X`` (utils.py:93-95)."""
+        lib = _lib.load()
+        X = self._check_dense(X, self.n)
+        F = X.shape[1]
+        with torch.cuda.device(self.device):
+            Y = torch.empty((self.n, F), dtype=torch.float32, device=self.device) if out is None else out
+            if F == 0:
+                return Y
+            ws = self._workspace(F)
+            _lib.check(lib.sgnn_spmm_csr_f32(
+                self.n, self.n, self.nnz, F, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
+                None if self.unit_weights else _lib.ptr(self.vals),
+                _lib.ptr(self.dinv) if scale_rows else None, _lib.ptr(self.dinv) if scale_cols else None,
+                _lib.ptr(X), X.stride(0) if X.shape[0] > 1 else F, _lib.ptr(Y), Y.stride(0) if self.n > 1 else F,
+                int(epilogue), _lib.ptr(ws), ws.numel(), _lib.current_stream(self.device)))
+        return Y
+
+    def propagate(self, X, order=1):
+        """``A_hat^order . X`` — the whole loop of utils.py:91-96 in ``order`` launches."""
+        order = int(order)
+        if order <= 0:
+            return X                       # range(order) is empty in the reference: X comes back as is
+        lib = _lib.load()
+        X = self._check_dense(X, self.n)
+        F = X.shape[1]
+        with torch.cuda.device(self.device):
+            Y = torch.empty((self.n, F), dtype=torch.float32, device=self.device)
+            if F == 0:
+                return Y
+            tmp = torch.empty((self.n, F), dtype=torch.float32, device=self.device) if order > 1 else None
+            ws = self._workspace(F)
+            _lib.check(lib.sgnn_spmm_chain_f32(
+                order, self.n, self.nnz, F, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
+                None if self.unit_weights else _lib.ptr(self.vals), _lib.ptr(self.dinv),
+                _lib.ptr(X), X.stride(0) if X.shape[0] > 1 else F, _lib.ptr(Y), F, _lib.ptr(tmp),
+                _lib.ptr(ws), ws.numel(), _lib.current_stream(self.device)))
+        return Y
+
+    # -------------------------------------------------------------- transpose
+    def transpose(self):
+        """NormAdj of ``A_hat^T`` (same dinv on both sides; needed by autograd)."""
+        if self._transposed is not None:
+            return self._transposed
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            t_rowptr = torch.empty_like(self.rowptr)
+            t_colidx = torch.empty_like(self.colidx)
+            t_vals = torch.empty_like(self.vals)
+            nbytes = lib.sgnn_transpose_workspace_bytes(self.n, self.nnz)
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            _lib.check(lib.sgnn_csr_transpose(
+                self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), _lib.ptr(self.vals),
+                _lib.ptr(t_rowptr), _lib.ptr(t_colidx), _lib.ptr(t_vals), _lib.ptr(ws), ws.numel(),
+                _lib.current_stream(self.device)))
+            same = bool(torch.equal(t_rowptr, self.rowptr) and torch.equal(t_colidx, self.colidx)
+                        and torch.equal(t_vals, self.vals))
+            del ws
+        self._symmetric = same
+        if same:
+            self._transposed = self
+        else:
+            t = NormAdj(self.n, t_rowptr, t_colidx, t_vals, self.deg, self.dinv,
+                        unit_weights=self.unit_weights, symmetric=False)
+            t._transposed = self
+            self._transposed = t
+        return self._transposed
+
+    @property
+    def symmetric(self):
+        if self._symmetric is None:
+            self.transpose()
+        return self._symmetric
+
+    # ------------------------------------------------------------------ export
+    def to_scipy(self):
+        """Host copy as a scipy CSR (tests and diagnostics)."""
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.vals.cpu().numpy(), self.colidx.cpu().numpy(), self.rowptr.cpu().numpy()),
+                             shape=(self.n, self.n))

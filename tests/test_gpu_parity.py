@@ -1,0 +1,328 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the
+golden vectors captured from the reference and against the CPU oracle.
+
+Bars: CSR row pointers, column indices, values and degrees bit for bit; dinv bit
+for bit against numpy's correctly rounded 1/sqrt; propagation within 1e-5
+relative — normwise and element-wise against ``|A_hat|^k |X|`` (golden_util).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from golden_util import abs_scale, hashed_features, load_golden, rel_err, scaled_err
+from oracle import sgnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+HAND = ["directed", "duplicates", "path_isolated", "selfloop", "star", "weight2"]
+
+
+@pytest.fixture(scope="module")
+def dev(gpu_device):
+    return gpu_device
+
+
+def _na():
+    from sgnn_amd.norm_adj import NormAdj
+    return NormAdj
+
+
+def _check_Y(Y, exp, rowptr, colidx, vals, dinv, X, order):
+    Y = Y.detach().cpu().numpy() if isinstance(Y, torch.Tensor) else np.asarray(Y)
+    assert Y.shape == exp.shape and Y.dtype == np.float32
+    scale = abs_scale(rowptr, colidx, vals, dinv, dinv, X, order)
+    assert rel_err(Y, exp) <= TOL
+    assert scaled_err(Y, exp, scale) <= TOL
+
+
+def _assert_csr_equal(adj, rowptr, colidx, vals, deg):
+    assert np.array_equal(adj.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(adj.colidx.cpu().numpy(), colidx)
+    assert np.array_equal(adj.vals.cpu().numpy(), vals)
+    assert np.array_equal(adj.deg.cpu().numpy(), deg)
+    with np.errstate(divide="ignore"):
+        dinv = (np.float32(1.0) / np.sqrt(deg.astype(np.float32))).astype(np.float32)
+    assert np.array_equal(adj.dinv.cpu().numpy(), dinv)
+
+
+# --------------------------------------------------------------------- build
+@pytest.mark.parametrize("name", HAND)
+def test_build_hand_graphs_bit_exact(dev, name):
+    g = load_golden("hand_graphs.npz")
+    n = int(g[f"{name}__n"])
+    r, c, v = g[f"{name}__row"], g[f"{name}__col"], g[f"{name}__val"]
+    adj = _na().from_coo(r, c, v, n, dev, strip_diag=True, drop_zeros=True)
+    _assert_csr_equal(adj, g[f"{name}__csr_rowptr"], g[f"{name}__csr_colidx"], g[f"{name}__csr_vals"],
+                      g[f"{name}__deg"])
+    # raw variant (diagonal kept, += 1) against the oracle's closed form
+    adj = _na().from_coo(r, c, v, n, dev)
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
+    _assert_csr_equal(adj, rowptr, colidx, vals, deg)
+
+
+def test_build_real_and_rmat_structures_bit_exact(dev):
+    for fname, weighted in (("cora_cites.npz", False), ("rmat2048.npz", False), ("rmat1024_directed_raw.npz", True)):
+        g = load_golden(fname)
+        n = int(g["n"])
+        r, c = g["row"], g["col"]
+        v = g["val"] if weighted else None
+        adj = _na().from_coo(r, c, v, n, dev, strip_diag=weighted, drop_zeros=weighted)
+        _assert_csr_equal(adj, g["csr_rowptr"], g["csr_colidx"], g["csr_vals"], g["deg"])
+        assert adj.nnz == g["csr_colidx"].size
+
+
+def test_build_modes_and_errors(dev):
+    NormAdj = _na()
+    r = np.array([0, 1, 2, 2, 3]); c = np.array([1, 0, 2, 3, 2]); v = np.array([1, 1, 5, 1, 1], np.float32)
+    for mode in (orc.SELF_LOOP_NONE, orc.SELF_LOOP_ADD, orc.SELF_LOOP_REMAINING):
+        adj = NormAdj.from_coo(r, c, v, 5, dev, self_loops=mode, zero_inf=(mode != orc.SELF_LOOP_ADD))
+        rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, 5, self_loops=mode)
+        assert np.array_equal(adj.rowptr.cpu().numpy(), rowptr)
+        assert np.array_equal(adj.colidx.cpu().numpy(), colidx)
+        assert np.array_equal(adj.vals.cpu().numpy(), vals)
+        assert np.array_equal(adj.deg.cpu().numpy(), deg)
+        got = adj.dinv.cpu().numpy()
+        if mode == orc.SELF_LOOP_NONE:        # node 4 isolated: 1/sqrt(0) = inf -> 0 (gcn_norm)
+            assert got[4] == 0.0
+    # empty graph: A + I = I, propagation is the identity
+    adj = NormAdj.from_coo(np.zeros(0, np.int64), np.zeros(0, np.int64), None, 7, dev)
+    assert adj.nnz == 7 and adj.unit_weights
+    X = torch.randn(7, 5, device=dev)
+    assert torch.equal(adj.propagate(X, 2), X)
+    with pytest.raises(ValueError):
+        NormAdj.from_coo(np.array([0, 9]), np.array([1, 0]), None, 5, dev)
+    with pytest.raises(ValueError):
+        NormAdj.from_coo(np.array([0, 1]), np.array([1]), None, 5, dev)
+    from sgnn_amd._lib import SgnnHipError
+    with pytest.raises(SgnnHipError):
+        NormAdj.from_coo(r, c, v, 5, "cpu")
+
+
+# --------------------------------------------------------------- propagation
+@pytest.mark.parametrize("name", HAND)
+def test_propagate_hand_graphs_vs_reference(dev, name):
+    from sgnn_amd import utils as su
+    g = load_golden("hand_graphs.npz")
+    n = int(g[f"{name}__n"])
+    r, c, v = g[f"{name}__row"], g[f"{name}__col"], g[f"{name}__val"]
+    X = hashed_features(n, 5, seed=int(g[f"{name}__xseed"]))
+    Xd = torch.from_numpy(X).to(dev)
+    # raw: handle built straight from the COO, as utils.coo_to_sparse_Tensor would
+    adj = su.coo_to_sparse_Tensor(sp.coo_matrix((v, (r, c)), shape=(n, n)), dev)
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
+    for order in (1, 2, 3):
+        Y = su.process_data_with_adjacency_high_order(adj, Xd, dev, order=order)
+        assert Y.is_contiguous() and not Y.requires_grad
+        _check_Y(Y, g[f"{name}__Y_raw_o{order}"], rowptr, colidx, vals, dinv, X, order)
+    assert torch.equal(Xd, torch.from_numpy(X).to(dev))          # input untouched
+    # stripped: the caller-side strip of model/SGNN.py:497-501 done in scipy, then the handle
+    S = orc.remove_self_loop(sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr())
+    adj = su.csr_to_sparse_Tensor(S, dev)
+    assert adj.shape[0] == n
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n, strip_diag=True, drop_zeros=True)
+    for order in (1, 2):
+        Y = su.process_data_with_adjacency_high_order(adj, Xd, dev, order=order)
+        _check_Y(Y, g[f"{name}__Y_strip_o{order}"], rowptr, colidx, vals, dinv, X, order)
+    Y1 = su.process_data_with_adjacency(adj, Xd, dev)
+    _check_Y(Y1, g[f"{name}__Y_strip_o1"], rowptr, colidx, vals, dinv, X, 1)
+
+
+def test_propagate_cora_vs_reference(dev):
+    from sgnn_amd import utils as su
+    g = load_golden("cora_cites.npz")
+    n = int(g["n"])
+    r, c = g["row"], g["col"]
+    A = sp.coo_matrix((np.ones(r.size, np.float32), (r, c)), shape=(n, n)).tocsr()
+    adj = su.csr_to_sparse_Tensor(A, dev)
+    X = hashed_features(n, int(g["F"]), seed=int(g["xseed"]))
+    rowptr, colidx, vals, dinv = g["csr_rowptr"], g["csr_colidx"], g["csr_vals"], adj.dinv.cpu().numpy()
+    for order in (1, 2, 3):
+        Y = su.process_data_with_adjacency_high_order(adj, torch.from_numpy(X), dev, order=order)   # X from the CPU
+        assert Y.device.type == "cuda"
+        _check_Y(Y, g[f"Y_o{order}"], rowptr, colidx, vals, dinv, X, order)
+
+
+def test_propagate_rmat_widths_vs_reference(dev):
+    g = load_golden("rmat2048.npz")
+    n = int(g["n"])
+    adj = _na().from_coo(g["row"], g["col"], None, n, dev)
+    dinv = adj.dinv.cpu().numpy()
+    for F in (1, 7, 64, 128):
+        X = hashed_features(n, F, seed=200 + F)
+        Y = adj.propagate(torch.from_numpy(X).to(dev), 1)
+        _check_Y(Y, g[f"Y_F{F}_o1"], g["csr_rowptr"], g["csr_colidx"], g["csr_vals"], dinv, X, 1)
+    X = hashed_features(n, 64, seed=264)
+    Y = adj.propagate(torch.from_numpy(X).to(dev), 2)
+    _check_Y(Y, g["Y_F64_o2"], g["csr_rowptr"], g["csr_colidx"], g["csr_vals"], dinv, X, 2)
+
+
+def test_propagate_wide_weight2_vs_reference(dev):
+    g = load_golden("rmat512_f602_w2.npz")
+    n = int(g["n"])
+    adj = _na().from_coo(g["row"], g["col"], g["val"], n, dev)
+    assert not adj.unit_weights
+    X = hashed_features(n, 602, seed=602)
+    Y = adj.propagate(torch.from_numpy(X).to(dev), 1)
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(g["row"], g["col"], g["val"], n)
+    _check_Y(Y, g["Y_F602_o1"], rowptr, colidx, vals, dinv, X, 1)
+
+
+def test_propagate_directed_raw_vs_reference(dev):
+    from sgnn_amd import utils as su
+    g = load_golden("rmat1024_directed_raw.npz")
+    n = int(g["n"])
+    r, c, v = g["row"], g["col"], g["val"]
+    X = hashed_features(n, 16, seed=16)
+    # through a genuine torch sparse COO tensor, as the reference's callers hold it
+    t = orc.coo_to_sparse_tensor(sp.coo_matrix((v, (r, c)), shape=(n, n))).to(dev)
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
+    for order in (1, 2):
+        Y = su.process_data_with_adjacency_high_order(t, torch.from_numpy(X).to(dev), dev, order=order)
+        _check_Y(Y, g[f"Y_raw_o{order}"], rowptr, colidx, vals, dinv, X, order)
+    assert getattr(t, "_sgnn_norm_adj", None) is not None         # converted once, then reused
+    adj = _na().from_coo(r, c, v, n, dev, strip_diag=True, drop_zeros=True)
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n, strip_diag=True, drop_zeros=True)
+    _check_Y(adj.propagate(torch.from_numpy(X).to(dev), 1), g["Y_strip_o1"], rowptr, colidx, vals, dinv, X, 1)
+
+
+def _hub_graph(n, seed):
+    """R-MAT plus two hubs whose rows are longer than one wavefront's segment."""
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    r, c = symmetric_simple_numpy(n, 6 * n, seed=seed)
+    rng = np.random.default_rng(seed)
+    hubs = []
+    for h, deg in ((3, min(n - 1, 5000)), (n // 2, min(n - 1, 1500))):
+        nb = rng.choice(np.setdiff1d(np.arange(n), [h]), size=deg, replace=False)
+        hubs.append((np.full(deg, h), nb))
+    hr = np.concatenate([a for a, b in hubs] + [b for a, b in hubs])
+    hc = np.concatenate([b for a, b in hubs] + [a for a, b in hubs])
+    return np.concatenate((r, hr)), np.concatenate((c, hc))
+
+
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 7, 8, 30, 64, 100, 128, 130, 256, 500, 602, 1433])
+def test_propagate_random_vs_oracle_all_widths(dev, F):
+    n = 6000
+    r, c = _hub_graph(n, seed=F)
+    v = np.ones(r.size, np.float32)                       # duplicates (hub edges that already existed) sum to 2
+    adj = _na().from_coo(r, c, v, n, dev)
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
+    assert np.array_equal(adj.rowptr.cpu().numpy(), rowptr) and np.array_equal(adj.colidx.cpu().numpy(), colidx)
+    assert int(np.diff(rowptr).max()) > 1024              # exercises the split-row path
+    X = np.random.default_rng(F).standard_normal((n, F)).astype(np.float32)
+    Y = adj.propagate(torch.from_numpy(X).to(dev), 1)
+    exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, X)
+    _check_Y(Y, exp, rowptr, colidx, vals, dinv, X, 1)
+    # bitwise reproducible run to run
+    Y2 = adj.propagate(torch.from_numpy(X).to(dev), 1)
+    assert torch.equal(Y, Y2)
+
+
+def test_strided_input_and_order_zero(dev):
+    n = 3000
+    r, c = _hub_graph(n, seed=77)
+    adj = _na().from_coo(r, c, None, n, dev)
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, np.ones(r.size, np.float32), n)
+    big = torch.randn(n, 200, device=dev)
+    Xv = big[:, 8:136]                                    # ld = 200, F = 128, 32-byte offset
+    Y = adj.propagate(Xv, 2)
+    Xh = Xv.cpu().numpy()
+    exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, Xh))
+    _check_Y(Y, exp, rowptr, colidx, vals, dinv, Xh, 2)
+    Xo = big[:, 3:10]                                     # 4-byte aligned only
+    Y = adj.propagate(Xo, 1)
+    _check_Y(Y, orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, Xo.cpu().numpy()), rowptr, colidx, vals, dinv,
+             Xo.cpu().numpy(), 1)
+    assert adj.propagate(big, 0) is big
+    with pytest.raises(ValueError):
+        adj.propagate(big[:10], 1)
+    with pytest.raises(ValueError):
+        adj.propagate(big.double(), 1)
+
+
+def test_size_independent_properties_mid_scale(dev):
+    """Identities that hold at any size: A_hat . D^1/2 1 = D^1/2 1, linearity, and
+    the weighted checksum (D^1/2 1)^T A_hat X = (D^1/2 1)^T X for symmetric A."""
+    from sgnn_amd.graphgen import rmat_undirected_device
+    n, F = 200_000, 96
+    row, col = rmat_undirected_device(n, 8_000_000, seed=5, device=dev)
+    adj = _na().from_coo(row, col, None, n, dev)
+    assert adj.symmetric
+    s = adj.deg.sqrt()
+    Y = adj.propagate(s[:, None].expand(n, 4).contiguous(), 1)
+    assert float(((Y - s[:, None]).abs() / s[:, None]).max()) <= TOL
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    X = torch.randn(n, F, device=dev, generator=g)
+    Z = torch.randn(n, F, device=dev, generator=g)
+    lhs = adj.propagate(2.0 * X - 0.5 * Z, 1)
+    rhs = 2.0 * adj.propagate(X, 1) - 0.5 * adj.propagate(Z, 1)
+    assert float((lhs - rhs).norm() / rhs.norm()) <= TOL
+    YX = adj.propagate(X, 1)
+    chk_l = (s.double()[:, None] * YX.double()).sum(0)
+    chk_r = (s.double()[:, None] * X.double()).sum(0)
+    absum = (s.double()[:, None] * X.double().abs()).sum(0)
+    assert float(((chk_l - chk_r).abs() / absum).max()) <= TOL
+
+
+# ----------------------------------------------------------------- operators
+def test_transpose_matches_scipy(dev):
+    g = load_golden("rmat1024_directed_raw.npz")
+    n = int(g["n"])
+    adj = _na().from_coo(g["row"], g["col"], g["val"], n, dev)
+    assert not adj.symmetric
+    T = adj.transpose()
+    M = adj.to_scipy().T.tocsr()
+    M.sort_indices()
+    assert np.array_equal(T.rowptr.cpu().numpy(), M.indptr)
+    assert np.array_equal(T.colidx.cpu().numpy(), M.indices)
+    assert np.array_equal(T.vals.cpu().numpy(), M.data)
+    assert T.transpose() is adj
+
+
+def test_sgconv_gcnconv_vs_pyg_semantics(dev):
+    from sgnn_amd.nn import GCNConv, SGConv
+    g = load_golden("rmat1024_directed_raw.npz")
+    n = int(g["n"])
+    ei = torch.from_numpy(np.stack((g["row"], g["col"])).astype(np.int64)).to(dev)
+    X = hashed_features(n, 24, seed=3)
+    Xd = torch.from_numpy(X).to(dev)
+    torch.manual_seed(0)
+    conv = SGConv(24, 5, K=2).to(dev)
+    out = conv(Xd, ei)
+    exp = orc.pyg_sgconv(X, ei.cpu().numpy(), conv.lin.weight.detach().cpu().numpy(),
+                         conv.lin.bias.detach().cpu().numpy(), K=2)
+    assert rel_err(out.detach().cpu().numpy(), exp) <= TOL
+    gcn = GCNConv(24, 6).to(dev)
+    with torch.no_grad():
+        gcn.bias.uniform_(-1, 1)
+    out = gcn(Xd, ei)
+    exp = orc.pyg_gcnconv(X, ei.cpu().numpy(), gcn.lin.weight.detach().cpu().numpy(), gcn.bias.detach().cpu().numpy())
+    assert rel_err(out.detach().cpu().numpy(), exp) <= TOL
+    assert set(dict(gcn.named_parameters())) == {"lin.weight", "bias"}
+    assert set(dict(conv.named_parameters())) == {"lin.weight", "lin.bias"}
+
+
+def test_gcnconv_backward_vs_dense_autograd(dev):
+    """A_hat^T . dY: the gradient w.r.t. the layer input and weights equals dense
+    autograd through the same normalised matrix (directed graph, so A_hat^T != A_hat)."""
+    from sgnn_amd.nn import GCNConv
+    g = load_golden("rmat1024_directed_raw.npz")
+    n = int(g["n"])
+    ei_np = np.stack((g["row"], g["col"])).astype(np.int64)
+    ei = torch.from_numpy(ei_np).to(dev)
+    src, dst, norm = orc.pyg_gcn_norm(ei_np, None, n)
+    M = torch.zeros(n, n, dtype=torch.float64)
+    M.index_put_((torch.from_numpy(dst), torch.from_numpy(src)), torch.from_numpy(norm).double(), accumulate=True)
+    torch.manual_seed(1)
+    gcn = GCNConv(12, 4).to(dev)
+    x = torch.randn(n, 12, device=dev, requires_grad=True)
+    w_out = torch.randn(n, 4, device=dev)
+    (gcn(x, ei) * w_out).sum().backward()
+    xd = x.detach().cpu().double().requires_grad_(True)
+    W = gcn.lin.weight.detach().cpu().double().requires_grad_(True)
+    b = gcn.bias.detach().cpu().double().requires_grad_(True)
+    ((M @ (xd @ W.t()) + b) * w_out.cpu().double()).sum().backward()
+    assert rel_err(x.grad.cpu().numpy(), xd.grad.numpy()) <= TOL
+    assert rel_err(gcn.lin.weight.grad.cpu().numpy(), W.grad.numpy()) <= 1e-4     # dense fp32 GEMM on top
+    assert rel_err(gcn.bias.grad.cpu().numpy(), b.grad.numpy()) <= 1e-4
