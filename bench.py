@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the sparse-propagation hot path: ``A_hat . X`` on a synthetic
+graph of Reddit's shape (n = 232 965, 114 615 892 stored entries, F = 602,
+order 1 — the shape the reference's Reddit configuration runs:
+config.json:480-503, GNN_tasks.py:76-80).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one call of ``process_data_with_adjacency_high_order`` on a prebuilt
+adjacency handle with X resident in HBM.  Rank 0 prints ONE JSON line.
+N > 1 (launched by torch.distributed.run, one rank per GPU) partitions the rows
+of the same graph over the ranks (strong scaling) and all-gathers the scaled
+row blocks of X over RCCL before each rank's SpMM.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, GB/s
+
+
+def algorithmic_bytes(n, nnz, F):
+    """Bytes one SpMM has to move at least once: CSR (int32 col + fp32 val per
+    stored entry, rowptr), both dinv vectors, X read once, Y written once."""
+    return nnz * 8 + (n + 1) * 4 + 2 * n * 4 + 2 * n * F * 4
+
+
+def cpu_baseline(n, F, seed, device, sample_edges, repeats=2):
+    """Time the CPU oracle (torch sparse-COO restatement of utils.py:81-96) on a
+    bounded sample: same node count, feature width and R-MAT parameters as the
+    GPU workload, fewer edges so that it finishes in tens of seconds."""
+    import torch
+    from oracle import sgnn_oracle as orc
+    from sgnn_amd.graphgen import rmat_undirected_device
+
+    row, col = rmat_undirected_device(n, sample_edges, seed=seed + 100, device=device)
+    idx = torch.stack((row, col)).cpu()
+    nnz = int(idx.shape[1])
+    adj = torch.sparse_coo_tensor(idx, torch.ones(nnz), (n, n))
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, F, generator=g)
+    best = float("inf")
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        orc.propagate_high_order(adj, X, 1)
+        best = min(best, time.perf_counter() - t0)
+    return {
+        "value": (nnz + n) * F / best,
+        "unit": "edge·feat/s",
+        "cores": int(torch.get_num_threads()),
+        "kind": "port",
+        "sample": f"reddit-shape R-MAT n={n} nnz(A)={nnz} F={F} order=1, one call = {best:.2f} s "
+                  f"(best of {repeats}); full op sequence incl. A+I and degree, as the reference redoes them per call",
+        "seconds": best,
+    }
+
+
+def load_traffic(workload):
+    """HBM bytes per SpMM launch from the committed PMC profile, if one matches."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get(workload)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="reddit", help="reddit | reddit128 | products | rmat10m | pubmed")
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-degree", type=int, default=None, help="clip hub degree (real Reddit's is ~21.7k)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-edges", type=int, default=10_000_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import SHAPES, rmat_undirected_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    n, E, F = SHAPES[args.workload]
+    t0 = time.perf_counter()
+    row, col = rmat_undirected_device(n, E, seed=args.seed, device=device, max_degree=args.max_degree)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    g = torch.Generator(device=device)
+    g.manual_seed(args.seed + 1)
+    X = torch.randn(n, F, device=device, generator=g)
+
+    extra = {}
+    if world == 1:
+        t0 = time.perf_counter()
+        adj = NormAdj.from_coo(row, col, None, n, device)
+        torch.cuda.synchronize()
+        extra["adjacency_build_ms"] = (time.perf_counter() - t0) * 1e3
+        del row, col
+        nnz = adj.nnz
+        step = lambda: adj.propagate(X, args.order)          # noqa: E731
+        max_deg = int((adj.rowptr[1:] - adj.rowptr[:-1]).max().item())
+    else:
+        from sgnn_amd.dist import PartitionedAdj
+        t0 = time.perf_counter()
+        padj = PartitionedAdj.from_coo(row, col, None, n, device, rank, world)
+        torch.cuda.synchronize()
+        extra["adjacency_build_ms"] = (time.perf_counter() - t0) * 1e3
+        del row, col
+        nnz = padj.global_nnz
+        Xl = X[padj.row_begin:padj.row_end].contiguous()
+        del X
+        step = lambda: padj.propagate(Xl, args.order)        # noqa: E731
+        max_deg = padj.global_max_degree
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ev_ms = ev0.elapsed_time(ev1) / args.steps              # HIP events on the launch stream
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        units = nnz * F * args.order                          # (E + n) . F per hop
+        b_alg = algorithmic_bytes(n, nnz, F) * args.order
+        achieved = b_alg / (ev_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Â·X SpMM edge·feat/s (Reddit F=602)" if args.workload == "reddit"
+                      else f"Â·X SpMM edge·feat/s ({args.workload})",
+            "value": units / (wall / args.steps),
+            "unit": "edge·feat/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}-shape symmetric R-MAT(0.57,0.19,0.19,0.05): n={n}, "
+                            f"nnz(A+I)={nnz}, F={F}, order={args.order}, max_degree={max_deg}, unit weights",
+                "rows": "one GPU" if world == 1 else f"row-partitioned over {world} GPUs, all-gather of scaled X blocks",
+                "graph_gen_s": round(t_gen, 2),
+                **{k: round(v, 2) for k, v in extra.items()},
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": load_traffic(args.workload) if world == 1 else None,
+                "algorithmic_bytes": b_alg,
+                "kernel_ms": ev_ms,
+                "gather_bytes_no_reuse": nnz * F * 4 * args.order,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, F, args.seed, device, args.cpu_sample_edges)
+        print(json.dumps(out, ensure_ascii=False), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

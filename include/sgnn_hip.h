@@ -44,7 +44,7 @@ extern "C" {
 /* self-loop modes */
 #define SGNN_LOOPS_NONE        0
 #define SGNN_LOOPS_ADD         1   /* A + I, diagonal value += 1: utils.py:83-86 */
-#define SGNN_LOOPS_REMAINING   2   /* diagonal = existing weight, else 1: torch_geometric gcn_norm's
+#define SGNN_LOOPS_REMAINING   2   /* diagonal = weight of the LAST diagonal input entry, else 1: torch_geometric gcn_norm's
                                       add_remaining_self_loops, reached from model/SGC.py:14, model/GCN.py:14,16 */
 
 /* Library version (major*10000 + minor*100 + patch).  No reference counterpart. */

@@ -93,7 +93,7 @@ def propagate(adjacency, X):
 # --------------------------------------------------------------------------
 SELF_LOOP_NONE = 0      # keep the diagonal as given
 SELF_LOOP_ADD = 1       # diag += 1   (utils.py:83-86: adjacency + self_loop)
-SELF_LOOP_REMAINING = 2  # diag = existing weight, else 1 (PyG add_remaining_self_loops)
+SELF_LOOP_REMAINING = 2  # diag = weight of the last existing loop entry, else 1 (PyG add_remaining_self_loops)
 
 
 def norm_csr(row, col, val, n, strip_diag=False, self_loops=SELF_LOOP_ADD, drop_zeros=False):
@@ -116,6 +116,17 @@ def norm_csr(row, col, val, n, strip_diag=False, self_loops=SELF_LOOP_ADD, drop_
     if strip_diag:
         keep = row != col
         row, col, val = row[keep], col[keep], val[keep]
+    if self_loops == SELF_LOOP_REMAINING:
+        # torch_geometric's add_remaining_self_loops: every diagonal entry is taken
+        # out, the loop weight of a node is that of its LAST diagonal entry (an
+        # index assignment), 1 where it has none
+        d = row == col
+        loop_w = np.ones(n, dtype=np.float32)
+        loop_w[row[d]] = val[d]
+        row = np.concatenate((row[~d], np.arange(n, dtype=np.int64)))
+        col = np.concatenate((col[~d], np.arange(n, dtype=np.int64)))
+        val = np.concatenate((val[~d], loop_w))
+        self_loops = SELF_LOOP_NONE
     # stable sort by (row, col); duplicates summed in fp32 in input order
     key = row * np.int64(n) + col
     order = np.argsort(key, kind="stable")

@@ -121,7 +121,8 @@ __global__ void k_make_keys(int64_t n, int64_t nnz_in, int64_t m, const int64_t*
 // run in sorted (= input, the sort is stable) order.
 __global__ void k_merge_runs(int64_t m, int64_t nnz_in, const uint64_t* __restrict__ keys,
                              const uint32_t* __restrict__ idx, const float* __restrict__ val, uint64_t sentinel,
-                             int self_loops, int drop_zeros, float* __restrict__ rsum, uint32_t* __restrict__ keep) {
+                             int cbits, int self_loops, int drop_zeros, float* __restrict__ rsum,
+                             uint32_t* __restrict__ keep) {
   int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (i >= m) return;
   uint64_t key = keys[i];
@@ -132,10 +133,14 @@ __global__ void k_merge_runs(int64_t m, int64_t nnz_in, const uint64_t* __restri
   }
   float s = 0.0f;
   bool any = false;
+  // REMAINING: a diagonal run keeps the weight of its last input entry (torch_geometric
+  // assigns loop weights by index, so later entries overwrite earlier ones), 1 if it has none
+  const bool assign = self_loops == SGNN_LOOPS_REMAINING && (key >> cbits) == (key & ((uint64_t(1) << cbits) - 1));
   for (int64_t j = i; j < m && keys[j] == key; ++j) {
     uint32_t id = idx[j];
     if (id < nnz_in) {
-      s += val ? val[id] : 1.0f;
+      float v = val ? val[id] : 1.0f;
+      s = assign ? v : s + v;
       any = true;
     } else if (self_loops == SGNN_LOOPS_ADD || !any) {
       s += 1.0f;  // the marker is the last entry of its run
@@ -374,24 +379,6 @@ __device__ __forceinline__ void write_row(const SpmmArgs& a, float* dst, int32_t
   }
 }
 
-// rows of at most kSeg entries: one wavefront per (row, feature tile)
-template <int V, int AL, int LPR, int C, int U>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_spmm_rows(SpmmArgs a) {
-  const int wave = threadIdx.x / kWave;
-  const int64_t row = int64_t(blockIdx.x) * kWavesPerBlock + wave;
-  if (row >= a.n_rows) return;
-  const int32_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
-  if (e1 - e0 > kSeg) return;  // handled by the segment kernels
-  const int f0 = blockIdx.y * (LPR * V * C);
-  float acc[C][V];
-#pragma unroll
-  for (int c = 0; c < C; ++c)
-#pragma unroll
-    for (int v = 0; v < V; ++v) acc[c][v] = 0.0f;
-  reduce_entries<V, AL, LPR, C, U>(a, e0, e1, f0, acc);
-  write_row<V, AL, LPR, C>(a, a.Y + row * a.ldy, int32_t(row), f0, acc, true);
-}
-
 // list the rows longer than kSeg and give each of their segments a partial slot
 __global__ void k_collect_long(SpmmArgs a) {
   int64_t row = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
@@ -410,11 +397,29 @@ __global__ void k_collect_long(SpmmArgs a) {
   }
 }
 
-// one wavefront per (segment, feature tile): unscaled partial sums
+// The SpMM kernel.  One wavefront per (work item, feature tile).  Blocks
+// [0, row_blocks) take the rows of at most kSeg entries, one row per wavefront,
+// and write Y directly; the blocks after them take the segments of the longer
+// rows and write unscaled partial sums (combined by k_spmm_combine).
 template <int V, int AL, int LPR, int C, int U>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_spmm_segments(SpmmArgs a) {
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_spmm(SpmmArgs a, unsigned row_blocks) {
   const int wave = threadIdx.x / kWave;
-  const int64_t s = int64_t(blockIdx.x) * kWavesPerBlock + wave;
+  const int f0 = blockIdx.y * (LPR * V * C);
+  float acc[C][V];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[c][v] = 0.0f;
+  if (blockIdx.x < row_blocks) {
+    const int64_t row = int64_t(blockIdx.x) * kWavesPerBlock + wave;
+    if (row >= a.n_rows) return;
+    const int32_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+    if (e1 - e0 > kSeg) return;  // cut into segments below
+    reduce_entries<V, AL, LPR, C, U>(a, e0, e1, f0, acc);
+    write_row<V, AL, LPR, C>(a, a.Y + row * a.ldy, int32_t(row), f0, acc, true);
+    return;
+  }
+  const int64_t s = int64_t(blockIdx.x - row_blocks) * kWavesPerBlock + wave;
   const int32_t nseg = min(a.counters[0], a.max_segs);
   if (s >= nseg) return;
   const int32_t row = a.seg_row[s];
@@ -422,14 +427,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_spmm_segments(SpmmArg
   const int32_t r0 = a.rowptr[row], r1 = a.rowptr[row + 1];
   const int32_t e0 = r0 + k * kSeg;
   const int32_t e1 = min(e0 + kSeg, r1);
-  const int f0 = blockIdx.y * (LPR * V * C);
-  float acc[C][V];
-#pragma unroll
-  for (int c = 0; c < C; ++c)
-#pragma unroll
-    for (int v = 0; v < V; ++v) acc[c][v] = 0.0f;
   reduce_entries<V, AL, LPR, C, U>(a, e0, e1, f0, acc);
-  // partial rows are dense [F] with 16-byte aligned starts only when F % 4 == 0: store scalars
+  // partial rows are dense [F]; their starts are 16-byte aligned only when F % 4 == 0: scalar stores
   const int lane = threadIdx.x & (kWave - 1);
   if (lane < LPR) {
     float* dst = a.partial + s * int64_t(a.F);
@@ -508,18 +507,14 @@ template <int V, int AL, int LPR, int C, int U>
 int launch_spmm(const SpmmArgs& a, hipStream_t st) {
   const int tile = LPR * V * C;
   const unsigned ftiles = unsigned((a.F + tile - 1) / tile);
-  dim3 block(kWave * kWavesPerBlock);
-  dim3 grid(unsigned((int64_t(a.n_rows) + kWavesPerBlock - 1) / kWavesPerBlock), ftiles);
-  hipLaunchKernelGGL((k_spmm_rows<V, AL, LPR, C, U>), grid, block, 0, st, a);
+  const unsigned row_blocks = unsigned((int64_t(a.n_rows) + kWavesPerBlock - 1) / kWavesPerBlock);
+  const unsigned seg_blocks = unsigned((int64_t(a.max_segs) + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipLaunchKernelGGL((k_spmm<V, AL, LPR, C, U>), dim3(row_blocks + seg_blocks, ftiles),
+                     dim3(kWave * kWavesPerBlock), 0, st, a, row_blocks);
   HIP_TRY(hipGetLastError());
-  if (a.max_segs > 0 && a.partial != nullptr) {
-    dim3 sgrid(unsigned((int64_t(a.max_segs) + kWavesPerBlock - 1) / kWavesPerBlock), ftiles);
-    hipLaunchKernelGGL((k_spmm_segments<V, AL, LPR, C, U>), sgrid, block, 0, st, a);
-    HIP_TRY(hipGetLastError());
-    dim3 cgrid(unsigned(a.max_long), unsigned((a.F + 255) / 256 > 8 ? 8 : (a.F + 255) / 256));
-    hipLaunchKernelGGL(k_spmm_combine, cgrid, dim3(256), 0, st, a);
-    HIP_TRY(hipGetLastError());
-  }
+  const unsigned fy = unsigned((a.F + 255) / 256 > 8 ? 8 : (a.F + 255) / 256);
+  hipLaunchKernelGGL(k_spmm_combine, dim3(unsigned(a.max_long), fy), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
 
@@ -629,8 +624,8 @@ int sgnn_build_norm_csr(int64_t n, int64_t nnz_in, const int64_t* row, const int
   size_t pb = w.prim_bytes;
   HIP_TRY(rocprim::radix_sort_pairs(w.prim, pb, w.keys_a, w.keys_b, w.idx_a, w.idx_b, size_t(m), 0u,
                                     unsigned(2 * cbits + 1), st));
-  hipLaunchKernelGGL(k_merge_runs, dim3(gm), dim3(T), 0, st, m, nnz_in, w.keys_b, w.idx_b, val, sentinel, self_loops,
-                     (flags & SGNN_DROP_ZEROS) ? 1 : 0, w.rsum, w.keep);
+  hipLaunchKernelGGL(k_merge_runs, dim3(gm), dim3(T), 0, st, m, nnz_in, w.keys_b, w.idx_b, val, sentinel, cbits,
+                     self_loops, (flags & SGNN_DROP_ZEROS) ? 1 : 0, w.rsum, w.keep);
   HIP_TRY(hipGetLastError());
   pb = w.prim_bytes;
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.keep, w.pos, 0u, size_t(m), rocprim::plus<uint32_t>(), st));
