@@ -50,6 +50,12 @@ extern "C" {
 /* Library version (major*10000 + minor*100 + patch).  No reference counterpart. */
 int sgnn_version(void);
 
+/* Override a kernel-selection policy for experiments (process-wide, not thread
+ * safe).  Keys: "tile" = feature-slice width in floats owned by one wavefront,
+ * "unroll" = row fetches issued back to back (2 or 4); value 0 restores the
+ * built-in policy.  No reference counterpart. */
+int sgnn_tune_set(const char* key, int value);
+
 /* Message of the calling thread's most recent failure ("" if none).
  * The reference raises Python exceptions; the host layer turns a negative
  * return code plus this string into a RuntimeError. */
@@ -141,6 +147,44 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
                         const float* dinv,
                         const float* X, int64_t ldx, float* Y, int64_t ldy, float* tmp,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Row-group form of a unit-weight CSR, and the SpMM kernel that uses it.
+ *
+ * Rows are ranked by degree and cut into groups of R (8 or 16); a group stores
+ * one merged column list with an R-bit mask per column.  The kernel fetches each
+ * listed row of X once for the whole group, which on power-law graphs removes
+ * 40-60 % of the row fetches that bound the plain CSR kernel.  Same arithmetic
+ * as sgnn_spmm_csr_f32 with vals == NULL (utils.py:93-95); every row is summed
+ * in ascending column order inside a segment of its group's list and the
+ * segments are added in order, so results are reproducible run to run (the
+ * order differs from the plain kernel's, results agree to fp32 rounding).
+ *
+ * sgnn_rowgroup_config   R to build the plan with for feature width F
+ *                        (0: this F is not supported, use sgnn_spmm_csr_f32)
+ * sgnn_rowgroup_build    fills `plan` (device, sgnn_rowgroup_plan_bytes) from the
+ *                        CSR; when the stream has drained, the first four int64
+ *                        of `plan` hold {merged entries, work items, partial
+ *                        slots, split groups} — the caller reads them once and
+ *                        passes the last three to every SpMM call
+ * sgnn_spmm_rowgroup_f32 workspace >= sgnn_spmm_rowgroup_workspace_bytes(slots, R, F)
+ * No reference counterpart for the plan itself: the reference keeps only the
+ * COO tensor (utils.py:54-62).
+ */
+int sgnn_rowgroup_config(int64_t F);
+size_t sgnn_rowgroup_plan_bytes(int64_t n_rows, int64_t nnz, int R);
+size_t sgnn_rowgroup_workspace_bytes(int64_t n_rows, int64_t nnz, int R);
+int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                        const int32_t* rowptr, const int32_t* colidx, int R,
+                        void* plan, size_t plan_bytes,
+                        void* workspace, size_t workspace_bytes, void* stream);
+size_t sgnn_spmm_rowgroup_workspace_bytes(int64_t slots, int R, int64_t F);
+int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, int R,
+                           const void* plan, size_t plan_bytes,
+                           int64_t items, int64_t slots, int64_t n_long,
+                           const float* dinv_row, const float* dinv_col,
+                           const float* X, int64_t ldx, float* Y, int64_t ldy,
+                           int epilogue, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[i, 0:F] = scale[i] * in[i, 0:F]  — utils.py:93 as a stand-alone pass (used
  * to pre-scale the row block a rank contributes to the all-gather). */

@@ -23,6 +23,7 @@ EPI_SCALE_ROW, EPI_SCALE_ROW2 = 0, 1
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "sgnn_version": (c_int, []),
+    "sgnn_tune_set": (c_int, [c_char_p, c_int]),
     "sgnn_last_error": (c_char_p, []),
     "sgnn_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgnn_build_norm_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -37,6 +38,15 @@ SIGNATURES = {
                                   c_void_p]),
     "sgnn_spmm_chain_f32": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sgnn_rowgroup_config": (c_int, [c_int64]),
+    "sgnn_rowgroup_plan_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "sgnn_rowgroup_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "sgnn_rowgroup_build": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                    c_void_p, c_size_t, c_void_p]),
+    "sgnn_spmm_rowgroup_workspace_bytes": (c_size_t, [c_int64, c_int, c_int64]),
+    "sgnn_spmm_rowgroup_f32": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t,
+                                       c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
 }
 

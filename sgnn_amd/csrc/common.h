@@ -1,0 +1,100 @@
+// Shared by the translation units of libsgnn_hip.so: error reporting, small host
+// helpers and the buffer-load primitives the SpMM kernels are built on.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "sgnn_hip.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LLVM's raw buffer loads, bound by name (the clang builtins for the 8- and
+// 16-byte forms return a splat of the first dword on this toolchain).
+__device__ float raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x2 raw_buffer_load_f32x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ f32x4 raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v4f32");
+
+namespace sgnn {
+
+// records the calling thread's error message and returns `code`
+int fail(int code, const std::string& msg);
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return ::sgnn::fail(SGNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+inline int ceil_log2(int64_t n) {
+  int b = 1;
+  while ((int64_t(1) << b) < n) ++b;
+  return b;
+}
+
+// carve consecutive 256-byte aligned regions out of one scratch buffer; with a
+// null base it only measures
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+  template <typename T>
+  T* take(size_t count) {
+    char* q = base ? base + off : nullptr;
+    off += align_up(count * sizeof(T));
+    return reinterpret_cast<T*>(q);
+  }
+};
+
+constexpr int kWave = 64;
+
+// untyped raw buffer over [base, base + bytes): stride 0, range-checked
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  i32x4 r = {int(uint32_t(b)), int(uint32_t(b >> 32) & 0xffffu), int(bytes), 0x00020000};
+  return r;
+}
+
+template <int V>
+__device__ __forceinline__ void buffer_load_vec(i32x4 rsrc, int voff, int soff, float (&r)[V]) {
+  if constexpr (V == 1) {
+    r[0] = raw_buffer_load_f32(rsrc, voff, soff, 0);
+  } else if constexpr (V == 2) {
+    f32x2 x = raw_buffer_load_f32x2(rsrc, voff, soff, 0);
+    r[0] = x[0];
+    r[1] = x[1];
+  } else {
+    f32x4 x = raw_buffer_load_f32x4(rsrc, voff, soff, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = x[i];
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void store_vec(float* p, const float (&r)[V], int aligned_for) {
+  if constexpr (V == 1) {
+    *p = r[0];
+  } else {
+    if (aligned_for >= V) {
+      typedef float vt __attribute__((ext_vector_type(V)));
+      vt v;
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = r[i];
+      *reinterpret_cast<vt*>(p) = v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) p[i] = r[i];
+    }
+  }
+}
+
+}  // namespace sgnn

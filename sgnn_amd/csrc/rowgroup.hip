@@ -1,0 +1,549 @@
+// Row-group SpMM: R output rows share every fetched row of X.
+//
+// The plain CSR kernel fetches one row of X per stored entry.  On graphs of
+// Reddit's shape that is ~277 GB of cache-level traffic per hop at F = 602,
+// served mostly from the Infinity Cache at its random-row rate, and it bounds the
+// kernel.  Rows of similar degree share many of their columns, so the rows are
+// ranked by degree and cut into groups of R; each group keeps ONE merged, sorted
+// column list with an R-bit mask per column saying which of its rows hold that
+// entry.  A wavefront walks the merged list, fetches each listed row of X once
+// and adds it into the accumulators of the rows whose bit is set (R x F/64
+// floats per lane, all in registers).  On the Reddit-shape benchmark graph the
+// merged lists hold 49 % (R = 16) of the entries, and the kernel time follows.
+//
+// Reference path served: the adj.mm of utils.py:94 for unit-weight adjacencies
+// (every dataset loader of the reference builds those, data_loader.py:545-549;
+// weighted graphs take the plain CSR kernel).
+#include <cstring>  // rocprim's texture iterator calls memset from host code
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace {
+using namespace sgnn;
+
+constexpr int kSegCols = 1024;      // merged columns one wavefront walks; longer lists are cut into segments
+constexpr int kWavesPerBlock = 4;
+
+struct Plan {
+  int32_t* grows;       // [G*R] row of (group, slot); -1 = empty slot
+  int32_t* gptr;        // [G+1] merged-list offsets
+  int32_t* gcol;        // [nnz] merged columns (capacity)
+  uint32_t* gmask;      // [nnz] which rows of the group hold the column
+  int32_t* item_group;  // [cap_items] work items: (group, segment of its merged list)
+  int32_t* item_m0;
+  int32_t* item_m1;
+  int32_t* item_out;    // -1: the item is its group's only one and writes Y; else partial slot
+  int32_t* long_group;  // [cap_long] groups with several items
+  int32_t* long_slot;   // [cap_long] first partial slot of the group
+  int64_t* counts;      // [4] merged, items, partial slots, long groups
+  int64_t G, cap_items, cap_long;
+  size_t total;
+};
+
+Plan carve_plan(void* base, int64_t n_rows, int64_t nnz, int R) {
+  Plan p{};
+  Carver c(base);
+  p.G = (n_rows + R - 1) / R;
+  p.cap_long = nnz / kSegCols + 1;
+  p.cap_items = p.G + p.cap_long;
+  p.counts = c.take<int64_t>(8);
+  p.grows = c.take<int32_t>(size_t(p.G) * R);
+  p.gptr = c.take<int32_t>(size_t(p.G) + 1);
+  p.gcol = c.take<int32_t>(size_t(nnz));
+  p.gmask = c.take<uint32_t>(size_t(nnz));
+  p.item_group = c.take<int32_t>(size_t(p.cap_items));
+  p.item_m0 = c.take<int32_t>(size_t(p.cap_items));
+  p.item_m1 = c.take<int32_t>(size_t(p.cap_items));
+  p.item_out = c.take<int32_t>(size_t(p.cap_items));
+  p.long_group = c.take<int32_t>(size_t(p.cap_long));
+  p.long_slot = c.take<int32_t>(size_t(p.cap_long));
+  p.total = c.off;
+  return p;
+}
+
+struct BuildWs {
+  uint32_t *dkey_a, *dkey_b, *drow_a, *drow_b;  // degree sort
+  int32_t* rank;
+  uint64_t *keys_a, *keys_b;
+  uint32_t *head, *pos;
+  int32_t* ogroup;
+  uint32_t *nseg, *first, *lseg, *slot0, *lflag, *lidx;
+  void* prim;
+  size_t prim_bytes;
+  size_t total;
+};
+
+BuildWs carve_build(void* base, int64_t n_rows, int64_t nnz, int R) {
+  BuildWs w{};
+  Carver c(base);
+  const int64_t G = (n_rows + R - 1) / R;
+  w.dkey_a = c.take<uint32_t>(n_rows);
+  w.dkey_b = c.take<uint32_t>(n_rows);
+  w.drow_a = c.take<uint32_t>(n_rows);
+  w.drow_b = c.take<uint32_t>(n_rows);
+  w.rank = c.take<int32_t>(n_rows);
+  w.keys_a = c.take<uint64_t>(nnz);
+  w.keys_b = c.take<uint64_t>(nnz);
+  w.head = c.take<uint32_t>(nnz);
+  w.pos = c.take<uint32_t>(nnz);
+  w.ogroup = c.take<int32_t>(nnz);
+  w.nseg = c.take<uint32_t>(G);
+  w.first = c.take<uint32_t>(G);
+  w.lseg = c.take<uint32_t>(G);
+  w.slot0 = c.take<uint32_t>(G);
+  w.lflag = c.take<uint32_t>(G);
+  w.lidx = c.take<uint32_t>(G);
+  size_t s1 = 0, s2 = 0, s3 = 0;
+  uint64_t* k64 = nullptr;
+  uint32_t* k32 = nullptr;
+  (void)rocprim::radix_sort_keys(nullptr, s1, k64, k64, size_t(nnz), 0u, 64u, hipStream_t(0));
+  (void)rocprim::radix_sort_pairs(nullptr, s2, k32, k32, k32, k32, size_t(n_rows), 0u, 32u, hipStream_t(0));
+  (void)rocprim::exclusive_scan(nullptr, s3, k32, k32, 0u, size_t(nnz > n_rows ? nnz : n_rows),
+                                rocprim::plus<uint32_t>(), hipStream_t(0));
+  w.prim_bytes = align_up(s1 > s2 ? (s1 > s3 ? s1 : s3) : (s2 > s3 ? s2 : s3));
+  w.prim = c.take<char>(w.prim_bytes);
+  w.total = c.off;
+  return w;
+}
+
+// ---- plan construction -------------------------------------------------------
+__global__ void k_deg_keys(int64_t n, const int32_t* __restrict__ rowptr, uint32_t* __restrict__ key,
+                           uint32_t* __restrict__ row) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  key[i] = 0xFFFFFFFFu - uint32_t(rowptr[i + 1] - rowptr[i]);   // ascending key = descending degree
+  row[i] = uint32_t(i);
+}
+
+__global__ void k_rank(int64_t n, int64_t slots, const uint32_t* __restrict__ order, int32_t* __restrict__ rank,
+                       int32_t* __restrict__ grows) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= slots) return;
+  if (i < n) {
+    rank[order[i]] = int32_t(i);
+    grows[i] = int32_t(order[i]);
+  } else {
+    grows[i] = -1;
+  }
+}
+
+// key of an entry = (group of its row, column, slot of its row in the group)
+__global__ void k_entry_keys(int64_t n, int64_t nnz, const int32_t* __restrict__ rowptr,
+                             const int32_t* __restrict__ colidx, const int32_t* __restrict__ rank, int R, int rbits,
+                             int cbits, uint64_t* __restrict__ keys) {
+  int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (e >= nnz) return;
+  int64_t lo = 0, hi = n;  // last row whose rowptr <= e
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (int64_t(rowptr[mid]) <= e) lo = mid; else hi = mid;
+  }
+  const uint32_t rk = uint32_t(rank[lo]);
+  keys[e] = (((uint64_t(rk / R) << cbits) | uint64_t(colidx[e])) << rbits) | uint64_t(rk % R);
+}
+
+__global__ void k_heads(int64_t nnz, const uint64_t* __restrict__ keys, int rbits, uint32_t* __restrict__ head) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= nnz) return;
+  head[i] = (i == 0 || (keys[i] >> rbits) != (keys[i - 1] >> rbits)) ? 1u : 0u;
+}
+
+__global__ void k_emit(int64_t nnz, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head,
+                       const uint32_t* __restrict__ pos, int rbits, int cbits, int32_t* __restrict__ gcol,
+                       uint32_t* __restrict__ gmask, int32_t* __restrict__ ogroup) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= nnz || !head[i]) return;
+  const uint64_t gc = keys[i] >> rbits;
+  uint32_t mask = 0;
+  for (int64_t j = i; j < nnz && (keys[j] >> rbits) == gc; ++j) mask |= 1u << uint32_t(keys[j] & ((1u << rbits) - 1));
+  const uint32_t p = pos[i];
+  gcol[p] = int32_t(gc & ((uint64_t(1) << cbits) - 1));
+  gmask[p] = mask;
+  ogroup[p] = int32_t(gc >> cbits);
+}
+
+__global__ void k_gptr(int64_t G, int64_t nnz, const uint32_t* __restrict__ head, const uint32_t* __restrict__ pos,
+                       const int32_t* __restrict__ ogroup, int32_t* __restrict__ gptr, int64_t* __restrict__ counts) {
+  int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  const int64_t merged = nnz > 0 ? int64_t(pos[nnz - 1]) + head[nnz - 1] : 0;
+  if (j > merged) return;
+  int64_t lo = j == 0 ? 0 : int64_t(ogroup[j - 1]) + 1;
+  int64_t hi = j == merged ? G : int64_t(ogroup[j]);
+  for (int64_t q = lo; q <= hi; ++q) gptr[q] = int32_t(j);
+  if (j == merged) counts[0] = merged;
+}
+
+__global__ void k_nseg(int64_t G, const int32_t* __restrict__ gptr, uint32_t* __restrict__ nseg,
+                       uint32_t* __restrict__ lseg, uint32_t* __restrict__ lflag) {
+  int64_t g = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (g >= G) return;
+  const int32_t len = gptr[g + 1] - gptr[g];
+  const uint32_t ns = len > kSegCols ? uint32_t((len + kSegCols - 1) / kSegCols) : 1u;
+  nseg[g] = ns;
+  lseg[g] = ns > 1 ? ns : 0u;
+  lflag[g] = ns > 1 ? 1u : 0u;
+}
+
+__global__ void k_items(int64_t G, const int32_t* __restrict__ gptr, const uint32_t* __restrict__ nseg,
+                        const uint32_t* __restrict__ first, const uint32_t* __restrict__ slot0,
+                        const uint32_t* __restrict__ lidx, int32_t* __restrict__ item_group,
+                        int32_t* __restrict__ item_m0, int32_t* __restrict__ item_m1, int32_t* __restrict__ item_out,
+                        int32_t* __restrict__ long_group, int32_t* __restrict__ long_slot,
+                        int64_t* __restrict__ counts) {
+  int64_t g = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t ns = nseg[g];
+  const int32_t b = gptr[g], e = gptr[g + 1];
+  for (uint32_t k = 0; k < ns; ++k) {
+    const uint32_t it = first[g] + k;
+    item_group[it] = int32_t(g);
+    item_m0[it] = b + int32_t(k) * kSegCols;
+    item_m1[it] = min(b + int32_t(k + 1) * kSegCols, e);
+    item_out[it] = ns > 1 ? int32_t(slot0[g] + k) : -1;
+  }
+  if (ns > 1) {
+    long_group[lidx[g]] = int32_t(g);
+    long_slot[lidx[g]] = int32_t(slot0[g]);
+  }
+  if (g == G - 1) {
+    counts[1] = int64_t(first[g]) + ns;
+    counts[2] = int64_t(slot0[g]) + (ns > 1 ? ns : 0);
+    counts[3] = int64_t(lidx[g]) + (ns > 1 ? 1 : 0);
+  }
+}
+
+// ---- the kernel ------------------------------------------------------------------
+struct RgArgs {
+  const int32_t *grows, *gptr, *gcol;
+  const uint32_t* gmask;
+  const int32_t *item_group, *item_m0, *item_m1, *item_out, *long_group, *long_slot;
+  const float *dinv_row, *dinv_col, *X;
+  float *Y, *partial;
+  int64_t ldx, ldy, x_bytes;
+  int32_t items, n_long, F, row_bytes, y_vec, epilogue;
+};
+
+template <int R, int V, int C, int UU, bool HASD>
+__device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, bool bigx, int32_t cols, uint32_t masks, float ws,
+                                        int k, const int (&boff)[C], float (&acc)[R][C][V]) {
+  float xv[UU][C][V];
+  uint32_t mk[UU];
+  float w[UU];
+#pragma unroll
+  for (int u = 0; u < UU; ++u) {
+    const int32_t col = __builtin_amdgcn_readlane(cols, k + u);
+    mk[u] = uint32_t(__builtin_amdgcn_readlane(int(masks), k + u));
+    if constexpr (HASD) w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), k + u));
+    if (bigx) {   // X spans 4 GiB or more: re-base the descriptor on the fetched row
+      const i32x4 rr = make_rsrc(a.X + int64_t(col) * a.ldx, uint32_t(a.F) * 4u);
+#pragma unroll
+      for (int c = 0; c < C; ++c) buffer_load_vec<V>(rr, boff[c], 0, xv[u][c]);
+    } else {
+      const int soff = col * a.row_bytes;
+#pragma unroll
+      for (int c = 0; c < C; ++c) buffer_load_vec<V>(rsrc, boff[c], soff, xv[u][c]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UU; ++u)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (mk[u] & (1u << r)) {   // wave-uniform: a scalar bit test and branch
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            if constexpr (HASD) acc[r][c][v] = fmaf(w[u], xv[u][c][v], acc[r][c][v]);
+            else acc[r][c][v] += xv[u][c][v];
+          }
+      }
+}
+
+// One wavefront per work item; lane l owns features (c*64 + l)*V .. +V of all R
+// accumulated rows.  Merged columns are taken 64 at a time through a VGPR (ids,
+// masks and, with HASD, dinv[col]) and handed to the scalar unit by v_readlane;
+// every row of a group is summed in ascending column order.
+template <int R, int V, int C, int U, bool HASD>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int item = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * kWavesPerBlock + int(threadIdx.x) / kWave);
+  if (item >= a.items) return;
+  const int g = a.item_group[item];
+  const int m0 = a.item_m0[item], m1 = a.item_m1[item];
+  const bool bigx = a.x_bytes >= (int64_t(1) << 32);
+  const i32x4 rsrc = make_rsrc(a.X, bigx ? 0u : uint32_t(a.x_bytes));
+  int boff[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) boff[c] = (c * kWave + lane) * V * 4;
+  float acc[R][C][V];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[r][c][v] = 0.0f;
+
+  int32_t ncols = 0;
+  uint32_t nmask = 0;
+  float nws = 0.0f;
+  if (m0 + lane < m1) {
+    ncols = a.gcol[m0 + lane];
+    nmask = a.gmask[m0 + lane];
+    if constexpr (HASD) nws = a.dinv_col[ncols];
+  }
+  for (int m = m0; m < m1; m += kWave) {
+    const int32_t cols = ncols;
+    const uint32_t masks = nmask;
+    const float ws = nws;
+    const int cnt = min(kWave, m1 - m);
+    const bool more = m + kWave < m1;
+    const bool mine = m + kWave + lane < m1;
+    if (more) {
+      ncols = mine ? a.gcol[m + kWave + lane] : 0;
+      nmask = mine ? a.gmask[m + kWave + lane] : 0u;
+    }
+    int k = 0;
+    if (cnt >= U) {
+      rg_step<R, V, C, U, HASD>(a, rsrc, bigx, cols, masks, ws, 0, boff, acc);
+      k = U;
+    }
+    if constexpr (HASD) {
+      if (more) nws = mine ? a.dinv_col[ncols] : 0.0f;   // the ids of the next batch have landed by now
+    }
+    for (; k + U <= cnt; k += U) rg_step<R, V, C, U, HASD>(a, rsrc, bigx, cols, masks, ws, k, boff, acc);
+    for (; k < cnt; ++k) rg_step<R, V, C, 1, HASD>(a, rsrc, bigx, cols, masks, ws, k, boff, acc);
+  }
+
+  const int out = a.item_out[item];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = a.grows[g * R + r];
+    if (row < 0) continue;
+    float* dst;
+    float dr = 1.0f;
+    bool scale = false;
+    int aligned_for;
+    if (out < 0) {
+      dst = a.Y + int64_t(row) * a.ldy;
+      scale = a.dinv_row != nullptr;
+      if (scale) dr = a.dinv_row[row];
+      aligned_for = a.y_vec;
+    } else {
+      dst = a.partial + (int64_t(out) * R + r) * a.F;
+      aligned_for = (a.F % 4 == 0) ? 4 : (a.F % 2 == 0 ? 2 : 1);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int f = (c * kWave + lane) * V;
+      if (f < a.F) {
+        float o[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float y = acc[r][c][v];
+          if (scale) {
+            y = y * dr;
+            if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+          }
+          o[v] = y;
+        }
+        store_vec<V>(dst + f, o, aligned_for);
+      }
+    }
+  }
+}
+
+// rows of a group cut into several items: add the items' partial rows in order
+template <int R>
+__global__ void k_rg_combine(RgArgs a) {
+  const int li = blockIdx.x;
+  if (li >= a.n_long) return;
+  const int g = a.long_group[li];
+  const int slot = a.long_slot[li];
+  const int len = a.gptr[g + 1] - a.gptr[g];
+  const int nseg = (len + kSegCols - 1) / kSegCols;
+  const int r = blockIdx.y;
+  const int row = a.grows[g * R + r];
+  if (row < 0) return;
+  const bool scale = a.dinv_row != nullptr;
+  const float dr = scale ? a.dinv_row[row] : 1.0f;
+  for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
+    float s = 0.0f;
+    for (int k = 0; k < nseg; ++k) s += a.partial[(int64_t(slot + k) * R + r) * a.F + f];
+    if (scale) {
+      s = s * dr;
+      if (a.epilogue == SGNN_EPI_SCALE_ROW2) s = s * dr;
+    }
+    a.Y[int64_t(row) * a.ldy + f] = s;
+  }
+}
+
+template <int R, int V, int C>
+int launch_rg(const RgArgs& a, bool hasd, hipStream_t st) {
+  const dim3 grid(unsigned((a.items + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWave * kWavesPerBlock);
+  if (hasd) hipLaunchKernelGGL((k_rg_spmm<R, V, C, 2, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_rg_spmm<R, V, C, 2, false>), grid, block, 0, st, a);
+  HIP_TRY(hipGetLastError());
+  if (a.n_long > 0) {
+    hipLaunchKernelGGL(k_rg_combine<R>, dim3(unsigned(a.n_long), R), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+  }
+  return SGNN_OK;
+}
+
+// (V, C) from F as sgnn_rowgroup_config reports it; R is the plan's
+template <int V>
+int dispatch_rg_c(const RgArgs& a, int R, int C, bool hasd, hipStream_t st) {
+  if (R == 16) {
+    if constexpr (V <= 2) {
+      if (C == 1) return launch_rg<16, V, 1>(a, hasd, st);
+      if (C == 2) return launch_rg<16, V, 2>(a, hasd, st);
+      if (C == 3) return launch_rg<16, V, 3>(a, hasd, st);
+      if (C == 4) return launch_rg<16, V, 4>(a, hasd, st);
+      if (C == 5) return launch_rg<16, V, 5>(a, hasd, st);
+    } else {
+      if (C == 1) return launch_rg<16, V, 1>(a, hasd, st);
+      if (C == 2) return launch_rg<16, V, 2>(a, hasd, st);
+    }
+  } else if (R == 8) {
+    if (C == 1) return launch_rg<8, V, 1>(a, hasd, st);
+    if (C == 2) return launch_rg<8, V, 2>(a, hasd, st);
+    if (C == 3) return launch_rg<8, V, 3>(a, hasd, st);
+    if (C == 4) return launch_rg<8, V, 4>(a, hasd, st);
+    if (C == 5) return launch_rg<8, V, 5>(a, hasd, st);
+  }
+  return fail(SGNN_ERR_UNSUPPORTED, "no row-group kernel for this (R, F)");
+}
+
+// widest vector that divides F and still keeps more than half the lanes busy
+bool rg_layout(int64_t F, int* V, int* C) {
+  int v = 1;
+  if (F % 4 == 0 && F / 4 > 32) v = 4;
+  else if (F % 2 == 0 && F / 2 > 32) v = 2;
+  const int64_t c = (F + int64_t(kWave) * v - 1) / (int64_t(kWave) * v);
+  if (c > 5) return false;
+  *V = v;
+  *C = int(c);
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgnn_rowgroup_config(int64_t F) {
+  int V, C;
+  if (F < 33 || !rg_layout(F, &V, &C)) return 0;
+  return (V * C <= 10) ? (F <= 128 ? 8 : 16) : 8;
+}
+
+size_t sgnn_rowgroup_plan_bytes(int64_t n_rows, int64_t nnz, int R) {
+  if (n_rows <= 0 || nnz < 0 || (R != 8 && R != 16)) return 0;
+  return carve_plan(nullptr, n_rows, nnz, R).total;
+}
+
+size_t sgnn_rowgroup_workspace_bytes(int64_t n_rows, int64_t nnz, int R) {
+  if (n_rows <= 0 || nnz < 0 || (R != 8 && R != 16)) return 0;
+  return carve_build(nullptr, n_rows, nnz > 0 ? nnz : 1, R).total;
+}
+
+int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                        int R, void* plan, size_t plan_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_rows <= 0 || n_cols <= 0 || nnz <= 0) return fail(SGNN_ERR_INVALID, "empty matrix");
+  if (R != 8 && R != 16) return fail(SGNN_ERR_INVALID, "R must be 8 or 16");
+  if (n_rows >= (int64_t(1) << 31) || n_cols >= (int64_t(1) << 31) || nnz >= (int64_t(1) << 31))
+    return fail(SGNN_ERR_INVALID, "size exceeds int32 index range");
+  if (!rowptr || !colidx || !plan || !workspace) return fail(SGNN_ERR_INVALID, "null pointer");
+  Plan p = carve_plan(plan, n_rows, nnz, R);
+  if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "row-group plan buffer too small");
+  BuildWs w = carve_build(workspace, n_rows, nnz, R);
+  if (workspace_bytes < w.total) return fail(SGNN_ERR_WORKSPACE, "row-group build workspace too small");
+  const int rbits = R == 16 ? 4 : 3;
+  const int cbits = ceil_log2(n_cols);
+  const int gbits = ceil_log2(p.G + 1);
+  if (rbits + cbits + gbits > 64) return fail(SGNN_ERR_INVALID, "key does not fit 64 bits");
+  const unsigned T = 256;
+  auto blocks = [&](int64_t items) { return dim3(unsigned((items + T - 1) / T)); };
+  HIP_TRY(hipMemsetAsync(p.counts, 0, 64, st));
+  // rank the rows by degree (stable: ties keep row order)
+  hipLaunchKernelGGL(k_deg_keys, blocks(n_rows), dim3(T), 0, st, n_rows, rowptr, w.dkey_a, w.drow_a);
+  HIP_TRY(hipGetLastError());
+  size_t pb = w.prim_bytes;
+  HIP_TRY(rocprim::radix_sort_pairs(w.prim, pb, w.dkey_a, w.dkey_b, w.drow_a, w.drow_b, size_t(n_rows), 0u, 32u, st));
+  hipLaunchKernelGGL(k_rank, blocks(p.G * R), dim3(T), 0, st, n_rows, p.G * R, w.drow_b, w.rank, p.grows);
+  HIP_TRY(hipGetLastError());
+  // sort the entries by (group, column, slot) and merge equal (group, column)
+  hipLaunchKernelGGL(k_entry_keys, blocks(nnz), dim3(T), 0, st, n_rows, nnz, rowptr, colidx, w.rank, R, rbits, cbits,
+                     w.keys_a);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.keys_a, w.keys_b, size_t(nnz), 0u, unsigned(rbits + cbits + gbits), st));
+  hipLaunchKernelGGL(k_heads, blocks(nnz), dim3(T), 0, st, nnz, w.keys_b, rbits, w.head);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.head, w.pos, 0u, size_t(nnz), rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_emit, blocks(nnz), dim3(T), 0, st, nnz, w.keys_b, w.head, w.pos, rbits, cbits, p.gcol, p.gmask,
+                     w.ogroup);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_gptr, blocks(nnz + 1), dim3(T), 0, st, p.G, nnz, w.head, w.pos, w.ogroup, p.gptr, p.counts);
+  HIP_TRY(hipGetLastError());
+  // work items
+  hipLaunchKernelGGL(k_nseg, blocks(p.G), dim3(T), 0, st, p.G, p.gptr, w.nseg, w.lseg, w.lflag);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.nseg, w.first, 0u, size_t(p.G), rocprim::plus<uint32_t>(), st));
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lseg, w.slot0, 0u, size_t(p.G), rocprim::plus<uint32_t>(), st));
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lflag, w.lidx, 0u, size_t(p.G), rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_items, blocks(p.G), dim3(T), 0, st, p.G, p.gptr, w.nseg, w.first, w.slot0, w.lidx,
+                     p.item_group, p.item_m0, p.item_m1, p.item_out, p.long_group, p.long_slot, p.counts);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+size_t sgnn_spmm_rowgroup_workspace_bytes(int64_t slots, int R, int64_t F) {
+  if (slots < 0 || F < 0 || R <= 0) return 0;
+  return align_up(size_t(slots) * size_t(R) * size_t(F) * 4 + 256);
+}
+
+int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, int R, const void* plan,
+                           size_t plan_bytes, int64_t items, int64_t slots, int64_t n_long, const float* dinv_row,
+                           const float* dinv_col, const float* X, int64_t ldx, float* Y, int64_t ldy, int epilogue,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_rows <= 0 || n_cols <= 0 || nnz <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty problem");
+  if (!plan || !X || !Y) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (ldx < F || ldy < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
+  if (reinterpret_cast<uintptr_t>(X) % 4 || reinterpret_cast<uintptr_t>(Y) % 4)
+    return fail(SGNN_ERR_INVALID, "X and Y must be 4-byte aligned");
+  if (epilogue != SGNN_EPI_SCALE_ROW && epilogue != SGNN_EPI_SCALE_ROW2)
+    return fail(SGNN_ERR_INVALID, "unknown epilogue mode");
+  int V, C;
+  if (!rg_layout(F, &V, &C)) return fail(SGNN_ERR_UNSUPPORTED, "F too wide for the row-group kernel");
+  Plan p = carve_plan(const_cast<void*>(plan), n_rows, nnz, R);
+  if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "row-group plan buffer too small");
+  if (items <= 0 || items > p.cap_items || slots < 0 || n_long < 0 || n_long > p.cap_long)
+    return fail(SGNN_ERR_INVALID, "item counts do not match the plan");
+  if (slots > 0 && (!workspace || workspace_bytes < sgnn_spmm_rowgroup_workspace_bytes(slots, R, F)))
+    return fail(SGNN_ERR_WORKSPACE, "row-group spmm workspace too small");
+  RgArgs a{};
+  a.grows = p.grows; a.gptr = p.gptr; a.gcol = p.gcol; a.gmask = p.gmask;
+  a.item_group = p.item_group; a.item_m0 = p.item_m0; a.item_m1 = p.item_m1; a.item_out = p.item_out;
+  a.long_group = p.long_group; a.long_slot = p.long_slot;
+  a.dinv_row = dinv_row; a.dinv_col = dinv_col; a.X = X; a.Y = Y; a.partial = static_cast<float*>(workspace);
+  a.ldx = ldx; a.ldy = ldy; a.x_bytes = ((n_cols - 1) * ldx + F) * 4;
+  a.items = int32_t(items); a.n_long = int32_t(n_long); a.F = int32_t(F);
+  a.row_bytes = a.x_bytes < (int64_t(1) << 32) ? int32_t(ldx * 4) : 0;
+  const uintptr_t py = reinterpret_cast<uintptr_t>(Y);
+  a.y_vec = (py % 16 == 0 && ldy % 4 == 0) ? 4 : ((py % 8 == 0 && ldy % 2 == 0) ? 2 : 1);
+  a.epilogue = epilogue;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool hasd = dinv_col != nullptr;
+  if (V == 4) return dispatch_rg_c<4>(a, R, C, hasd, st);
+  if (V == 2) return dispatch_rg_c<2>(a, R, C, hasd, st);
+  return dispatch_rg_c<1>(a, R, C, hasd, st);
+}
+
+}  // extern "C"

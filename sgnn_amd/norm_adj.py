@@ -49,6 +49,8 @@ class NormAdj:
         self._symmetric = symmetric
         self._transposed = None
         self._ws = {}
+        self._plans = {}                  # R -> row-group plan (built on first use)
+        self.use_rowgroup = True          # unit-weight graphs, supported widths: see _rowgroup_plan
 
     # the reference's callers only ever look at .shape[0] of the adjacency handle
     # (model/SGNN.py:33)
@@ -144,6 +146,63 @@ class NormAdj:
             self._ws = {F: ws}            # keep one: callers alternate between few widths
         return ws
 
+    def _rowgroup_plan(self, F):
+        """Row-group plan for feature width F, or None when the plain CSR kernel
+        must be used (weighted adjacency, unsupported width, switched off)."""
+        if not (self.use_rowgroup and self.unit_weights) or self.nnz == 0:
+            return None
+        lib = _lib.load()
+        R = lib.sgnn_rowgroup_config(F)
+        if R == 0:
+            return None
+        plan = self._plans.get(R)
+        if plan is None:
+            with torch.cuda.device(self.device):
+                pbytes = lib.sgnn_rowgroup_plan_bytes(self.n, self.nnz, R)
+                buf = torch.empty(pbytes, dtype=torch.uint8, device=self.device)
+                wbytes = lib.sgnn_rowgroup_workspace_bytes(self.n, self.nnz, R)
+                ws = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
+                _lib.check(lib.sgnn_rowgroup_build(
+                    self.n, self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), R,
+                    _lib.ptr(buf), pbytes, _lib.ptr(ws), wbytes, _lib.current_stream(self.device)))
+                counts = buf[:32].view(torch.int64).cpu()       # synchronises
+                del ws
+            merged, items, slots, n_long = (int(v) for v in counts)
+            plan = dict(R=R, buf=buf, bytes=pbytes, merged=merged, items=items, slots=slots, n_long=n_long, ws={})
+            self._plans[R] = plan
+        return plan
+
+    def _rowgroup_ws(self, plan, F):
+        ws = plan["ws"].get(F)
+        if ws is None:
+            nbytes = _lib.load().sgnn_spmm_rowgroup_workspace_bytes(plan["slots"], plan["R"], F)
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            plan["ws"] = {F: ws}
+        return ws
+
+    def _hop(self, X, ldx, Y, ldy, F, scale_rows, scale_cols, epilogue):
+        """Enqueue one SpMM launch sequence: the row-group kernel when a plan
+        exists for this width, the plain CSR kernel otherwise."""
+        lib = _lib.load()
+        dinv = _lib.ptr(self.dinv)
+        plan = self._rowgroup_plan(F)
+        if plan is not None:
+            ws = self._rowgroup_ws(plan, F)
+            _lib.check(lib.sgnn_spmm_rowgroup_f32(
+                self.n, self.n, self.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
+                plan["items"], plan["slots"], plan["n_long"],
+                dinv if scale_rows else None, dinv if scale_cols else None,
+                _lib.ptr(X), ldx, _lib.ptr(Y), ldy, int(epilogue), _lib.ptr(ws), ws.numel(),
+                _lib.current_stream(self.device)))
+            return
+        ws = self._workspace(F)
+        _lib.check(lib.sgnn_spmm_csr_f32(
+            self.n, self.n, self.nnz, F, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
+            None if self.unit_weights else _lib.ptr(self.vals),
+            dinv if scale_rows else None, dinv if scale_cols else None,
+            _lib.ptr(X), ldx, _lib.ptr(Y), ldy, int(epilogue), _lib.ptr(ws), ws.numel(),
+            _lib.current_stream(self.device)))
+
     def _check_dense(self, X, rows):
         if not isinstance(X, torch.Tensor) or X.dim() != 2:
             raise ValueError("X must be a 2-D tensor")
@@ -160,41 +219,49 @@ class NormAdj:
     # ------------------------------------------------------------------ apply
     def spmm(self, X, scale_rows=True, scale_cols=True, epilogue=_lib.EPI_SCALE_ROW, out=None):
         """One hop: ``diag(dinv) . (A+I) . diag(dinv) . X`` (utils.py:93-95)."""
-        lib = _lib.load()
         X = self._check_dense(X, self.n)
         F = X.shape[1]
         with torch.cuda.device(self.device):
             Y = torch.empty((self.n, F), dtype=torch.float32, device=self.device) if out is None else out
             if F == 0:
                 return Y
-            ws = self._workspace(F)
-            _lib.check(lib.sgnn_spmm_csr_f32(
-                self.n, self.n, self.nnz, F, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
-                None if self.unit_weights else _lib.ptr(self.vals),
-                _lib.ptr(self.dinv) if scale_rows else None, _lib.ptr(self.dinv) if scale_cols else None,
-                _lib.ptr(X), X.stride(0) if X.shape[0] > 1 else F, _lib.ptr(Y), Y.stride(0) if self.n > 1 else F,
-                int(epilogue), _lib.ptr(ws), ws.numel(), _lib.current_stream(self.device)))
+            self._hop(X, X.stride(0) if X.shape[0] > 1 else F, Y, Y.stride(0) if self.n > 1 else F, F,
+                      scale_rows, scale_cols, epilogue)
         return Y
 
     def propagate(self, X, order=1):
-        """``A_hat^order . X`` — the whole loop of utils.py:91-96 in ``order`` launches."""
+        """``A_hat^order . X`` — the whole loop of utils.py:91-96 in ``order`` SpMM
+        launches.  Between hops the two row scalings of the reference (utils.py:95
+        of one hop, utils.py:93 of the next) are folded into the epilogue, so no
+        separate pass touches the intermediates."""
         order = int(order)
         if order <= 0:
             return X                       # range(order) is empty in the reference: X comes back as is
-        lib = _lib.load()
         X = self._check_dense(X, self.n)
         F = X.shape[1]
         with torch.cuda.device(self.device):
             Y = torch.empty((self.n, F), dtype=torch.float32, device=self.device)
             if F == 0:
                 return Y
+            if self._rowgroup_plan(F) is None:
+                # plain CSR kernel: the library's own K-hop chain
+                lib = _lib.load()
+                tmp = torch.empty((self.n, F), dtype=torch.float32, device=self.device) if order > 1 else None
+                ws = self._workspace(F)
+                _lib.check(lib.sgnn_spmm_chain_f32(
+                    order, self.n, self.nnz, F, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
+                    None if self.unit_weights else _lib.ptr(self.vals), _lib.ptr(self.dinv),
+                    _lib.ptr(X), X.stride(0) if X.shape[0] > 1 else F, _lib.ptr(Y), F, _lib.ptr(tmp),
+                    _lib.ptr(ws), ws.numel(), _lib.current_stream(self.device)))
+                return Y
             tmp = torch.empty((self.n, F), dtype=torch.float32, device=self.device) if order > 1 else None
-            ws = self._workspace(F)
-            _lib.check(lib.sgnn_spmm_chain_f32(
-                order, self.n, self.nnz, F, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
-                None if self.unit_weights else _lib.ptr(self.vals), _lib.ptr(self.dinv),
-                _lib.ptr(X), X.stride(0) if X.shape[0] > 1 else F, _lib.ptr(Y), F, _lib.ptr(tmp),
-                _lib.ptr(ws), ws.numel(), _lib.current_stream(self.device)))
+            src, lds = X, (X.stride(0) if X.shape[0] > 1 else F)
+            for h in range(order):
+                last = h == order - 1
+                dst = Y if (order - 1 - h) % 2 == 0 else tmp      # the last hop lands in Y
+                self._hop(src, lds, dst, F, F, True, h == 0,
+                          _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2)
+                src, lds = dst, F
         return Y
 
     # -------------------------------------------------------------- transpose
@@ -223,6 +290,7 @@ class NormAdj:
             t = NormAdj(self.n, t_rowptr, t_colidx, t_vals, self.deg, self.dinv,
                         unit_weights=self.unit_weights, symmetric=False)
             t._transposed = self
+            t.use_rowgroup = self.use_rowgroup
             self._transposed = t
         return self._transposed
 

@@ -207,6 +207,7 @@ def test_propagate_random_vs_oracle_all_widths(dev, F):
     r, c = _hub_graph(n, seed=F)
     v = np.ones(r.size, np.float32)                       # duplicates (hub edges that already existed) sum to 2
     adj = _na().from_coo(r, c, v, n, dev)
+    assert not adj.unit_weights                           # weighted: always the plain CSR kernel
     rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
     assert np.array_equal(adj.rowptr.cpu().numpy(), rowptr) and np.array_equal(adj.colidx.cpu().numpy(), colidx)
     assert int(np.diff(rowptr).max()) > 1024              # exercises the split-row path
@@ -217,6 +218,36 @@ def test_propagate_random_vs_oracle_all_widths(dev, F):
     # bitwise reproducible run to run
     Y2 = adj.propagate(torch.from_numpy(X).to(dev), 1)
     assert torch.equal(Y, Y2)
+
+
+@pytest.mark.parametrize("F", [1, 7, 33, 34, 64, 100, 128, 130, 256, 500, 602, 640, 1280, 1433])
+@pytest.mark.parametrize("order", [1, 3])
+def test_unit_weight_graph_rowgroup_and_plain_kernels(dev, F, order):
+    """Unit-weight graphs take the row-group kernel where it supports F; it and the
+    plain CSR kernel must both meet the oracle (and each is bitwise reproducible)."""
+    from sgnn_amd import _lib
+    n = 5000
+    r, c = _hub_graph(n, seed=1000 + F)
+    key = np.unique(r.astype(np.int64) * n + c)
+    r, c = key // n, key % n
+    adj = _na().from_coo(r, c, None, n, dev)
+    assert adj.unit_weights
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, np.ones(r.size, np.float32), n)
+    X = np.random.default_rng(F).standard_normal((n, F)).astype(np.float32)
+    exp = X
+    for _ in range(order):
+        exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, exp)
+    Xd = torch.from_numpy(X).to(dev)
+    supported = _lib.load().sgnn_rowgroup_config(F) != 0
+    for flag in (True, False):
+        adj.use_rowgroup = flag
+        Y = adj.propagate(Xd, order)
+        _check_Y(Y, exp, rowptr, colidx, vals, dinv, X, order)
+        assert torch.equal(Y, adj.propagate(Xd, order))
+        assert (adj._rowgroup_plan(F) is not None) == (flag and supported)
+    if supported:
+        plan = adj._rowgroup_plan.__self__._plans[_lib.load().sgnn_rowgroup_config(F)]
+        assert 0 < plan["merged"] <= adj.nnz and plan["n_long"] >= 1     # hubs: split groups exercised
 
 
 def test_strided_input_and_order_zero(dev):

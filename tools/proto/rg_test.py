@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Prototype driver: row-group SpMM (R rows share each fetched row of X)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from sgnn_amd import NormAdj  # noqa: E402
+from sgnn_amd.graphgen import SHAPES, rmat_undirected_device  # noqa: E402
+
+
+class RgArgs(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ("item_group", "item_m0", "item_m1", "item_out", "grows", "gcol", "gmask", "dinv", "X", "Y", "partial")] + \
+               [("items", ctypes.c_int32), ("F", ctypes.c_int32), ("row_bytes", ctypes.c_int32), ("x_bytes", ctypes.c_uint32)]
+
+
+def build_groups(adj, R, seg, sort_by_degree=True):
+    dev = adj.device
+    n = adj.n
+    deg = (adj.rowptr[1:] - adj.rowptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    cols = adj.colidx.long()
+    if sort_by_degree:
+        order = torch.argsort(deg, descending=True, stable=True)
+    else:
+        order = torch.arange(n, device=dev)
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(n, device=dev)
+    G = (n + R - 1) // R
+    grows = torch.full((G * R,), -1, dtype=torch.int32, device=dev)
+    grows[:n] = order.int()
+    rk = rank[rows]
+    key = (rk // R) * n + cols
+    bit = (1 << (rk % R))
+    key, perm = torch.sort(key)
+    bit = bit[perm]
+    ukey, inv = torch.unique_consecutive(key, return_inverse=True)
+    mask = torch.zeros(ukey.numel(), dtype=torch.int64, device=dev)
+    mask.index_add_(0, inv, bit)
+    gid = ukey // n
+    gcol = (ukey % n).int()
+    gptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    gptr[1:] = torch.cumsum(torch.bincount(gid, minlength=G), 0)
+    glen = gptr[1:] - gptr[:-1]
+    nseg = (glen + seg - 1) // seg
+    nseg = torch.clamp(nseg, min=1)
+    item_group = torch.repeat_interleave(torch.arange(G, device=dev), nseg)
+    first = torch.cumsum(nseg, 0) - nseg
+    k = torch.arange(item_group.numel(), device=dev) - first[item_group]
+    m0 = gptr[item_group] + k * seg
+    m1 = torch.minimum(m0 + seg, gptr[item_group + 1])
+    multi = nseg[item_group] > 1
+    slot = torch.cumsum(multi.long(), 0) - 1
+    item_out = torch.where(multi, slot, torch.full_like(slot, -1))
+    return dict(grows=grows, gcol=gcol, gmask=mask.int(), item_group=item_group.int(), m0=m0.int(), m1=m1.int(),
+                item_out=item_out.int(), nslots=int(multi.sum()), nseg=nseg, first=first, G=G)
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "reddit"
+    maxdeg = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
+    Fo = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    dev = torch.device("cuda:0")
+    lib = ctypes.CDLL(os.path.join(HERE, "librg.so"))
+    n, E, F = SHAPES[wl]
+    if Fo:
+        F = Fo
+    row, col = rmat_undirected_device(n, E, seed=1, device=dev, max_degree=maxdeg)
+    adj = NormAdj.from_coo(row, col, None, n, dev)
+    del row, col
+    X = torch.randn(n, F, device=dev)
+    ref = adj.propagate(X, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        adj.propagate(X, 1)
+    e1.record(); torch.cuda.synchronize()
+    deg = adj.rowptr[1:] - adj.rowptr[:-1]
+    print(f"{wl} n={n} nnz={adj.nnz} F={F} max_deg={int(deg.max())}: plain CSR kernel {e0.elapsed_time(e1)/3:.3f} ms", flush=True)
+    Xs = (X * adj.dinv[:, None]).contiguous()
+    cfgs = ((16, 2, 1024, True), (16, 12, 1024, True), (32, 12, 1024, True), (32, 13, 1024, True), (32, 15, 1024, True)) if F > 128 else \
+           ((8, 2, 1024, True), (16, 2, 1024, True), (16, 4, 1024, True), (32, 2, 1024, True), (32, 4, 1024, True), (32, 2, 1024, False))
+    for R, U, seg, sortdeg in cfgs:
+        g = build_groups(adj, R, seg, sortdeg)
+        Y = torch.zeros(n, F, device=dev)
+        partial = torch.zeros(max(g["nslots"], 1) * R * F, device=dev)
+        a = RgArgs()
+        for name, t in (("item_group", g["item_group"]), ("item_m0", g["m0"]), ("item_m1", g["m1"]),
+                        ("item_out", g["item_out"]), ("grows", g["grows"]), ("gcol", g["gcol"]), ("gmask", g["gmask"]),
+                        ("dinv", adj.dinv), ("X", Xs), ("Y", Y), ("partial", partial)):
+            setattr(a, name, t.data_ptr())
+        a.items = g["item_group"].numel(); a.F = F; a.row_bytes = F * 4; a.x_bytes = n * F * 4
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = lib.rg_spmm(R, U, ctypes.byref(a), st)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        # combine partials (torch, prototype only)
+        io = g["item_out"].long(); sel = io >= 0
+        if sel.any():
+            P = partial.view(-1, R, F)
+            grp = g["item_group"].long()[sel]
+            rowsel = g["grows"].view(-1, R).long()[grp]          # [items, R]
+            valid = rowsel >= 0
+            Yp = torch.zeros(n, F, device=dev)
+            Yp.index_add_(0, rowsel[valid], P[io[sel]][valid])
+            long_rows = torch.unique(rowsel[valid])
+            Y[long_rows] = Yp[long_rows] * adj.dinv[long_rows, None]
+        err = float((Y - ref).norm() / ref.norm())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            lib.rg_spmm(R, U, ctypes.byref(a), st)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(f"R={R:2d} U={U} seg={seg} sortdeg={sortdeg}: merged={g['gcol'].numel()} ({100*g['gcol'].numel()/adj.nnz:.1f}%) "
+              f"items={a.items} {ms:7.3f} ms  rel.err {err:.1e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
