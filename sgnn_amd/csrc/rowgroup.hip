@@ -23,8 +23,17 @@
 namespace {
 using namespace sgnn;
 
-constexpr int kSegCols = 1024;      // merged columns one wavefront walks; longer lists are cut into segments
 constexpr int kWavesPerBlock = 4;
+
+// Merged columns one wavefront walks; longer lists are cut into segments of this
+// length.  A wavefront works through its list serially, so small graphs get short
+// segments (enough wavefronts to hide latency) and large ones long segments
+// (fewer partial rows to combine).
+int seg_cols_for(int64_t nnz) {
+  int seg = 64;
+  while (seg < 1024 && nnz / seg > 32768) seg *= 2;
+  return seg;
+}
 
 struct Plan {
   int32_t* grows;       // [G*R] row of (group, slot); -1 = empty slot
@@ -37,7 +46,7 @@ struct Plan {
   int32_t* item_out;    // -1: the item is its group's only one and writes Y; else partial slot
   int32_t* long_group;  // [cap_long] groups with several items
   int32_t* long_slot;   // [cap_long] first partial slot of the group
-  int64_t* counts;      // [4] merged, items, partial slots, long groups
+  int64_t* counts;      // [8] merged, items, partial slots, long groups, segment length
   int64_t G, cap_items, cap_long;
   size_t total;
 };
@@ -46,7 +55,7 @@ Plan carve_plan(void* base, int64_t n_rows, int64_t nnz, int R) {
   Plan p{};
   Carver c(base);
   p.G = (n_rows + R - 1) / R;
-  p.cap_long = nnz / kSegCols + 1;
+  p.cap_long = nnz / seg_cols_for(nnz) + 1;
   p.cap_items = p.G + p.cap_long;
   p.counts = c.take<int64_t>(8);
   p.grows = c.take<int32_t>(size_t(p.G) * R);
@@ -175,7 +184,7 @@ __global__ void k_gptr(int64_t G, int64_t nnz, const uint32_t* __restrict__ head
   if (j == merged) counts[0] = merged;
 }
 
-__global__ void k_nseg(int64_t G, const int32_t* __restrict__ gptr, uint32_t* __restrict__ nseg,
+__global__ void k_nseg(int64_t G, int kSegCols, const int32_t* __restrict__ gptr, uint32_t* __restrict__ nseg,
                        uint32_t* __restrict__ lseg, uint32_t* __restrict__ lflag) {
   int64_t g = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (g >= G) return;
@@ -186,7 +195,7 @@ __global__ void k_nseg(int64_t G, const int32_t* __restrict__ gptr, uint32_t* __
   lflag[g] = ns > 1 ? 1u : 0u;
 }
 
-__global__ void k_items(int64_t G, const int32_t* __restrict__ gptr, const uint32_t* __restrict__ nseg,
+__global__ void k_items(int64_t G, int kSegCols, const int32_t* __restrict__ gptr, const uint32_t* __restrict__ nseg,
                         const uint32_t* __restrict__ first, const uint32_t* __restrict__ slot0,
                         const uint32_t* __restrict__ lidx, int32_t* __restrict__ item_group,
                         int32_t* __restrict__ item_m0, int32_t* __restrict__ item_m1, int32_t* __restrict__ item_out,
@@ -211,6 +220,7 @@ __global__ void k_items(int64_t G, const int32_t* __restrict__ gptr, const uint3
     counts[1] = int64_t(first[g]) + ns;
     counts[2] = int64_t(slot0[g]) + (ns > 1 ? ns : 0);
     counts[3] = int64_t(lidx[g]) + (ns > 1 ? 1 : 0);
+    counts[4] = kSegCols;
   }
 }
 
@@ -222,11 +232,11 @@ struct RgArgs {
   const float *dinv_row, *dinv_col, *X;
   float *Y, *partial;
   int64_t ldx, ldy, x_bytes;
-  int32_t items, n_long, F, row_bytes, y_vec, epilogue;
+  int32_t items, n_long, F, row_bytes, y_vec, epilogue, seg;
 };
 
-template <int R, int V, int C, int UU, bool HASD>
-__device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, bool bigx, int32_t cols, uint32_t masks, float ws,
+template <int R, int V, int C, int UU, bool HASD, bool BIGX>
+__device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, int32_t cols, uint32_t masks, float ws,
                                         int k, const int (&boff)[C], float (&acc)[R][C][V]) {
   float xv[UU][C][V];
   uint32_t mk[UU];
@@ -236,7 +246,7 @@ __device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, bool bigx, 
     const int32_t col = __builtin_amdgcn_readlane(cols, k + u);
     mk[u] = uint32_t(__builtin_amdgcn_readlane(int(masks), k + u));
     if constexpr (HASD) w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), k + u));
-    if (bigx) {   // X spans 4 GiB or more: re-base the descriptor on the fetched row
+    if constexpr (BIGX) {   // X spans 4 GiB or more: re-base the descriptor on the fetched row
       const i32x4 rr = make_rsrc(a.X + int64_t(col) * a.ldx, uint32_t(a.F) * 4u);
 #pragma unroll
       for (int c = 0; c < C; ++c) buffer_load_vec<V>(rr, boff[c], 0, xv[u][c]);
@@ -265,15 +275,14 @@ __device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, bool bigx, 
 // accumulated rows.  Merged columns are taken 64 at a time through a VGPR (ids,
 // masks and, with HASD, dinv[col]) and handed to the scalar unit by v_readlane;
 // every row of a group is summed in ascending column order.
-template <int R, int V, int C, int U, bool HASD>
+template <int R, int V, int C, int U, bool HASD, bool BIGX>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int item = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * kWavesPerBlock + int(threadIdx.x) / kWave);
   if (item >= a.items) return;
   const int g = a.item_group[item];
   const int m0 = a.item_m0[item], m1 = a.item_m1[item];
-  const bool bigx = a.x_bytes >= (int64_t(1) << 32);
-  const i32x4 rsrc = make_rsrc(a.X, bigx ? 0u : uint32_t(a.x_bytes));
+  const i32x4 rsrc = make_rsrc(a.X, BIGX ? 0u : uint32_t(a.x_bytes));
   int boff[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) boff[c] = (c * kWave + lane) * V * 4;
@@ -306,14 +315,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
     }
     int k = 0;
     if (cnt >= U) {
-      rg_step<R, V, C, U, HASD>(a, rsrc, bigx, cols, masks, ws, 0, boff, acc);
+      rg_step<R, V, C, U, HASD, BIGX>(a, rsrc, cols, masks, ws, 0, boff, acc);
       k = U;
     }
     if constexpr (HASD) {
       if (more) nws = mine ? a.dinv_col[ncols] : 0.0f;   // the ids of the next batch have landed by now
     }
-    for (; k + U <= cnt; k += U) rg_step<R, V, C, U, HASD>(a, rsrc, bigx, cols, masks, ws, k, boff, acc);
-    for (; k < cnt; ++k) rg_step<R, V, C, 1, HASD>(a, rsrc, bigx, cols, masks, ws, k, boff, acc);
+    for (; k + U <= cnt; k += U) rg_step<R, V, C, U, HASD, BIGX>(a, rsrc, cols, masks, ws, k, boff, acc);
+    for (; k < cnt; ++k) rg_step<R, V, C, 1, HASD, BIGX>(a, rsrc, cols, masks, ws, k, boff, acc);
   }
 
   const int out = a.item_out[item];
@@ -362,7 +371,7 @@ __global__ void k_rg_combine(RgArgs a) {
   const int g = a.long_group[li];
   const int slot = a.long_slot[li];
   const int len = a.gptr[g + 1] - a.gptr[g];
-  const int nseg = (len + kSegCols - 1) / kSegCols;
+  const int nseg = (len + a.seg - 1) / a.seg;
   const int r = blockIdx.y;
   const int row = a.grows[g * R + r];
   if (row < 0) return;
@@ -381,9 +390,17 @@ __global__ void k_rg_combine(RgArgs a) {
 
 template <int R, int V, int C>
 int launch_rg(const RgArgs& a, bool hasd, hipStream_t st) {
+  // row fetches in flight per wavefront: about 8 vector loads
+  constexpr int U = C == 1 ? 8 : (C == 2 ? 4 : 2);
   const dim3 grid(unsigned((a.items + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWave * kWavesPerBlock);
-  if (hasd) hipLaunchKernelGGL((k_rg_spmm<R, V, C, 2, true>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((k_rg_spmm<R, V, C, 2, false>), grid, block, 0, st, a);
+  const bool bigx = a.x_bytes >= (int64_t(1) << 32);
+  if (hasd) {
+    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, true, false>), grid, block, 0, st, a);
+  } else {
+    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, false, false>), grid, block, 0, st, a);
+  }
   HIP_TRY(hipGetLastError());
   if (a.n_long > 0) {
     hipLaunchKernelGGL(k_rg_combine<R>, dim3(unsigned(a.n_long), R), dim3(256), 0, st, a);
@@ -490,7 +507,8 @@ int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32
   hipLaunchKernelGGL(k_gptr, blocks(nnz + 1), dim3(T), 0, st, p.G, nnz, w.head, w.pos, w.ogroup, p.gptr, p.counts);
   HIP_TRY(hipGetLastError());
   // work items
-  hipLaunchKernelGGL(k_nseg, blocks(p.G), dim3(T), 0, st, p.G, p.gptr, w.nseg, w.lseg, w.lflag);
+  const int seg = seg_cols_for(nnz);
+  hipLaunchKernelGGL(k_nseg, blocks(p.G), dim3(T), 0, st, p.G, seg, p.gptr, w.nseg, w.lseg, w.lflag);
   HIP_TRY(hipGetLastError());
   pb = w.prim_bytes;
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.nseg, w.first, 0u, size_t(p.G), rocprim::plus<uint32_t>(), st));
@@ -498,7 +516,7 @@ int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lseg, w.slot0, 0u, size_t(p.G), rocprim::plus<uint32_t>(), st));
   pb = w.prim_bytes;
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lflag, w.lidx, 0u, size_t(p.G), rocprim::plus<uint32_t>(), st));
-  hipLaunchKernelGGL(k_items, blocks(p.G), dim3(T), 0, st, p.G, p.gptr, w.nseg, w.first, w.slot0, w.lidx,
+  hipLaunchKernelGGL(k_items, blocks(p.G), dim3(T), 0, st, p.G, seg, p.gptr, w.nseg, w.first, w.slot0, w.lidx,
                      p.item_group, p.item_m0, p.item_m1, p.item_out, p.long_group, p.long_slot, p.counts);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
@@ -539,6 +557,7 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   const uintptr_t py = reinterpret_cast<uintptr_t>(Y);
   a.y_vec = (py % 16 == 0 && ldy % 4 == 0) ? 4 : ((py % 8 == 0 && ldy % 2 == 0) ? 2 : 1);
   a.epilogue = epilogue;
+  a.seg = seg_cols_for(nnz);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool hasd = dinv_col != nullptr;
   if (V == 4) return dispatch_rg_c<4>(a, R, C, hasd, st);
