@@ -1,0 +1,285 @@
+"""Row-partitioned propagation over the GPUs of one node (one process per GPU).
+
+The reference's own multi-GPU mode is replication: every rank loads the whole
+graph and recomputes the whole ``A_hat . X`` (main.py:39-41, model/SGNN.py:518-520
+— the DDP wrapper is bypassed through ``.module.run``), so there is nothing to be
+compatible with beyond the result.  Here the rows of ``A_hat`` are split into
+``world`` contiguous blocks of about equal stored entries; rank p owns block p of
+the matrix, of ``dinv`` and of X / Y.  One hop is
+
+  1. scale the local rows of X by the local ``dinv``          (utils.py:93)
+  2. all-gather the scaled blocks into one padded buffer      (RCCL over xGMI)
+  3. SpMM of the local row block against the gathered buffer  (utils.py:94)
+  4. scale the local output rows by the local ``dinv``        (utils.py:95, fused)
+
+Blocks are padded to a common row count so that the exchange is ONE
+``all_gather_into_tensor`` of equal pieces; the local CSR's column ids are
+remapped once into the padded index space.  Pre-scaling before the exchange means
+``dinv`` itself never travels.  With ``slices > 1`` the feature dimension is cut
+into column slices and the all-gather of slice s+1 runs on a side stream while
+slice s is multiplied, which hides most of the exchange behind the SpMM.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .norm_adj import NormAdj
+
+
+def balanced_row_splits(counts, world):
+    """Split points r_0=0 <= ... <= r_world=n such that every block holds about
+    the same number of stored entries.  ``counts`` = entries per row (1-D tensor
+    or array); deterministic, so every rank computes the same answer."""
+    c = torch.as_tensor(counts).to(torch.int64).cpu()
+    n = c.numel()
+    csum = torch.cumsum(c, 0)
+    total = int(csum[-1]) if n else 0
+    splits = [0]
+    for p in range(1, world):
+        target = (total * p + world - 1) // world
+        r = int(torch.searchsorted(csum, torch.tensor(target, dtype=torch.int64)).item()) + 1
+        splits.append(min(max(r, splits[-1]), n))
+    splits.append(n)
+    return splits
+
+
+def pad_index_map(splits):
+    """Column id -> position in the padded gather buffer (block p starts at
+    p * max_rows)."""
+    world = len(splits) - 1
+    max_rows = max(splits[p + 1] - splits[p] for p in range(world))
+    n = splits[-1]
+    m = np.empty(n, dtype=np.int64)
+    for p in range(world):
+        m[splits[p]:splits[p + 1]] = p * max_rows + np.arange(splits[p + 1] - splits[p])
+    return m, max_rows
+
+
+class PartitionedAdj:
+    """Rank-local row block of ``A + I`` plus what one hop needs."""
+
+    def __init__(self, local, splits, rank, world, n, global_nnz, global_max_degree, group=None):
+        self.local = local                      # NormAdj-like over (rows_local x padded columns)
+        self.splits, self.rank, self.world, self.n = splits, rank, world, n
+        self.row_begin, self.row_end = splits[rank], splits[rank + 1]
+        self.max_rows = max(splits[p + 1] - splits[p] for p in range(world))
+        self.global_nnz, self.global_max_degree = global_nnz, global_max_degree
+        self.group = group
+        self._gather = {}
+        self._comm_stream = None
+
+    # ------------------------------------------------------------------ build
+    @classmethod
+    def from_coo(cls, row, col, val, n, device, rank, world, group=None, local_factory=None):
+        """Every rank passes the same COO (entries of other ranks' rows are
+        dropped here).  ``local_factory`` is a test hook that builds the local
+        block object from ``(row_local, col_padded, val, n_rows, n_cols, dinv_seed)``;
+        the default builds the device CSR through the C ABI."""
+        row = torch.as_tensor(row).to(torch.int64)
+        col = torch.as_tensor(col).to(torch.int64)
+        counts = torch.bincount(row, minlength=n) + 1            # + the self-loop every row gets
+        splits = balanced_row_splits(counts, world)
+        r0, r1 = splits[rank], splits[rank + 1]
+        mine = (row >= r0) & (row < r1)
+        lrow, lcol = row[mine], col[mine]
+        lval = None if val is None else torch.as_tensor(val)[mine]
+        global_nnz = int(counts.sum().item())
+        global_max_degree = int(counts.max().item())
+        padmap, max_rows = pad_index_map(splits)
+        if local_factory is not None:
+            local = local_factory(lrow - r0, lcol, lval, r1 - r0, n, r0, padmap, max_rows * world)
+        else:
+            local = _LocalBlock.build(lrow, lcol, lval, n, r0, r1, padmap, max_rows * world, device)
+        return cls(local, splits, rank, world, n, global_nnz, global_max_degree, group)
+
+    # ------------------------------------------------------------------ apply
+    def _buffers(self, F, device, dtype):
+        key = (F, device, dtype)
+        b = self._gather.get(key)
+        if b is None:
+            rows = self.max_rows * self.world
+            b = [torch.zeros((rows, F), dtype=dtype, device=device) for _ in range(2)]
+            self._gather = {key: b}
+        return b
+
+    def _all_gather(self, full, piece):
+        if self.world == 1:
+            return
+        if piece.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no GPU all-gather: stage through the host (several ranks sharing
+            # one GPU in tests; production runs use the nccl backend = RCCL)
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host.view(-1), piece.cpu().reshape(-1), group=self.group)
+            full.copy_(host)
+            return
+        # on the GPU the piece is sent in place (it already sits in its slot of `full`)
+        inp = piece if piece.is_cuda else piece.clone()
+        dist.all_gather_into_tensor(full.view(-1), inp.reshape(-1), group=self.group)
+
+    def propagate(self, X_local, order=1, slices=1):
+        """``A_hat^order . X`` for the local rows; X_local = this rank's rows of X.
+        Returns this rank's rows of the result."""
+        order = int(order)
+        if order <= 0:
+            return X_local
+        rows = self.row_end - self.row_begin
+        if X_local.shape[0] != rows:
+            raise ValueError(f"rank {self.rank} owns {rows} rows, got {X_local.shape[0]}")
+        F = X_local.shape[1]
+        if slices > 1 and X_local.is_cuda:
+            return self._propagate_sliced(X_local, order, slices)
+        bufs = self._buffers(F, X_local.device, X_local.dtype)
+        lo = self.rank * self.max_rows
+        src = X_local
+        out = None
+        for h in range(order):
+            full = bufs[h % 2]
+            piece = full[lo:lo + self.max_rows]
+            if h == 0:
+                self.local.scale_rows_into(src, piece[:rows])           # utils.py:93
+            # later hops: the previous epilogue already wrote the doubly scaled rows into `piece`
+            self._all_gather(full, piece)
+            last = h == order - 1
+            if last:
+                out = torch.empty((rows, F), dtype=X_local.dtype, device=X_local.device)
+                self.local.spmm_into(full, out, final=True)
+            else:
+                nxt = bufs[(h + 1) % 2][lo:lo + rows]
+                self.local.spmm_into(full, nxt, final=False)            # epilogue: (s*d)*d
+        return out
+
+    def _propagate_sliced(self, X_local, order, slices):
+        """Feature-sliced pipeline: exchange slice s+1 while slice s is multiplied."""
+        rows = self.row_end - self.row_begin
+        F = X_local.shape[1]
+        dev = X_local.device
+        bounds = [(F * s) // slices for s in range(slices + 1)]
+        bounds = [b - b % 4 for b in bounds[:-1]] + [F]
+        bounds = sorted(set(bounds))
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        comm = self._comm_stream
+        main = torch.cuda.current_stream(dev)
+        lo = self.rank * self.max_rows
+        cur = X_local
+        for h in range(order):
+            last = h == order - 1
+            out = torch.empty((rows, F), dtype=X_local.dtype, device=dev)
+            fulls, events = [], []
+            for s in range(len(bounds) - 1):
+                f0, f1 = bounds[s], bounds[s + 1]
+                full = torch.empty((self.max_rows * self.world, f1 - f0), dtype=X_local.dtype, device=dev)
+                piece = full[lo:lo + self.max_rows]
+                if rows < self.max_rows:
+                    piece[rows:].zero_()
+                if h == 0:
+                    self.local.scale_rows_into(cur[:, f0:f1], piece[:rows])
+                else:
+                    piece[:rows].copy_(cur[:, f0:f1])                   # already doubly scaled
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ready)
+                    self._all_gather(full, piece)
+                    done = torch.cuda.Event()
+                    done.record(comm)
+                full.record_stream(comm)
+                fulls.append(full)
+                events.append(done)
+            for s in range(len(bounds) - 1):
+                f0, f1 = bounds[s], bounds[s + 1]
+                main.wait_event(events[s])
+                self.local.spmm_into(fulls[s], out[:, f0:f1], final=last)
+            cur = out
+        return cur
+
+
+class _LocalBlock:
+    """Device CSR of one row block over the padded column space."""
+
+    def __init__(self, adj, dinv_local, n_rows, n_cols_padded):
+        self.adj = adj                  # NormAdj whose rows are the local rows (square trick, see build)
+        self.dinv = dinv_local
+        self.n_rows, self.n_cols = n_rows, n_cols_padded
+        self._plans = {}
+        self._ws = {}
+
+    @classmethod
+    def build(cls, lrow, lcol, lval, n, r0, r1, padmap, n_cols_padded, device):
+        # Build the block as an n x n matrix that holds only the local rows (the
+        # library's builder is square: it inserts the self-loops and computes the
+        # row degree), then cut the local rows out and remap the columns.
+        full = NormAdj.from_coo(lrow.to(device), lcol.to(device), None if lval is None else lval.to(device),
+                                n, device)
+        rp = full.rowptr
+        e0, e1 = int(rp[r0].item()), int(rp[r1].item())
+        rowptr = (rp[r0:r1 + 1] - e0).contiguous()
+        pm = torch.from_numpy(padmap).to(device)
+        colidx = pm[full.colidx[e0:e1].long()].to(torch.int32).contiguous()
+        vals = full.vals[e0:e1].contiguous()
+        block = NormAdj(r1 - r0, rowptr, colidx, vals, full.deg[r0:r1].contiguous(), full.dinv[r0:r1].contiguous(),
+                        unit_weights=full.unit_weights)
+        return cls(block, block.dinv, r1 - r0, n_cols_padded)
+
+    def scale_rows_into(self, src, dst):
+        lib = _lib.load()
+        src = src if src.stride(1) == 1 else src.contiguous()
+        _lib.check(lib.sgnn_row_scale_f32(self.n_rows, src.shape[1], _lib.ptr(self.dinv), _lib.ptr(src), src.stride(0),
+                                          _lib.ptr(dst), dst.stride(0), _lib.current_stream(src.device)))
+
+    def _plan(self, F):
+        a = self.adj
+        if not a.unit_weights or a.nnz == 0:
+            return None
+        lib = _lib.load()
+        R = lib.sgnn_rowgroup_config(F)
+        if R == 0:
+            return None
+        plan = self._plans.get(R)
+        if plan is None:
+            dev = a.device
+            pbytes = lib.sgnn_rowgroup_plan_bytes(self.n_rows, a.nnz, R)
+            buf = torch.empty(pbytes, dtype=torch.uint8, device=dev)
+            wbytes = lib.sgnn_rowgroup_workspace_bytes(self.n_rows, a.nnz, R)
+            ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sgnn_rowgroup_build(self.n_rows, self.n_cols, a.nnz, _lib.ptr(a.rowptr), _lib.ptr(a.colidx),
+                                               R, _lib.ptr(buf), pbytes, _lib.ptr(ws), wbytes,
+                                               _lib.current_stream(dev)))
+            merged, items, slots, n_long = (int(v) for v in buf[:32].view(torch.int64).cpu())
+            plan = dict(R=R, buf=buf, bytes=pbytes, items=items, slots=slots, n_long=n_long)
+            self._plans[R] = plan
+        return plan
+
+    def spmm_into(self, full, out, final):
+        """out[rows_local, F] = dinv . (block . full), or (dinv . s) . dinv when not final."""
+        lib = _lib.load()
+        a = self.adj
+        F = full.shape[1]
+        dev = full.device
+        epi = _lib.EPI_SCALE_ROW if final else _lib.EPI_SCALE_ROW2
+        plan = self._plan(F)
+        if plan is not None:
+            nbytes = lib.sgnn_spmm_rowgroup_workspace_bytes(plan["slots"], plan["R"], F)
+            ws = self._ws.get(("rg", F))
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+                self._ws[("rg", F)] = ws
+            _lib.check(lib.sgnn_spmm_rowgroup_f32(
+                self.n_rows, self.n_cols, a.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
+                plan["items"], plan["slots"], plan["n_long"], _lib.ptr(self.dinv), None,
+                _lib.ptr(full), full.stride(0), _lib.ptr(out), out.stride(0), epi, _lib.ptr(ws), ws.numel(),
+                _lib.current_stream(dev)))
+            return
+        nbytes = lib.sgnn_spmm_workspace_bytes(self.n_rows, a.nnz, F)
+        ws = self._ws.get(("csr", F))
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+            self._ws[("csr", F)] = ws
+        _lib.check(lib.sgnn_spmm_csr_f32(
+            self.n_rows, self.n_cols, a.nnz, F, _lib.ptr(a.rowptr), _lib.ptr(a.colidx),
+            None if a.unit_weights else _lib.ptr(a.vals), _lib.ptr(self.dinv), None,
+            _lib.ptr(full), full.stride(0), _lib.ptr(out), out.stride(0), epi, _lib.ptr(ws), ws.numel(),
+            _lib.current_stream(dev)))

@@ -1,0 +1,109 @@
+"""Row-partitioned propagation with world_size > 1 over gloo on the CPU.
+
+The partitioning, padding, column remap, pre-scaling, all-gather and the hop
+chaining are the product's (sgnn_amd.dist); the rank-local SpMM is injected from
+the CPU oracle because there is no GPU here — the GPU variant of this test runs
+the real kernels on two ranks that share cuda:0.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import sgnn_oracle as orc
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleBlock:
+    """CPU stand-in for the device row block: same interface, oracle arithmetic."""
+
+    def __init__(self, lrow, lcol, lval, n_rows, n, r0, padmap, n_cols_padded):
+        v = np.ones(lrow.numel(), np.float32) if lval is None else lval.numpy().astype(np.float32)
+        rowptr, colidx, vals, deg, dinv = orc.norm_csr(lrow.numpy() + r0, lcol.numpy(), v, n)
+        e0, e1 = rowptr[r0], rowptr[r0 + n_rows]
+        self.rowptr = (rowptr[r0:r0 + n_rows + 1] - e0).astype(np.int32)
+        self.colidx = padmap[colidx[e0:e1]].astype(np.int32)
+        self.vals = vals[e0:e1]
+        self.dinv = dinv[r0:r0 + n_rows]
+        self.n_rows, self.n_cols = n_rows, n_cols_padded
+
+    def scale_rows_into(self, src, dst):
+        dst.copy_(src * torch.from_numpy(self.dinv)[:, None])
+
+    def spmm_into(self, full, out, final):
+        import scipy.sparse as sp
+        A = sp.csr_matrix((self.vals.astype(np.float64), self.colidx, self.rowptr), shape=(self.n_rows, self.n_cols))
+        s = (A @ full.numpy().astype(np.float64)).astype(np.float32)
+        y = s * self.dinv[:, None]
+        if not final:
+            y = y * self.dinv[:, None]
+        out.copy_(torch.from_numpy(y.astype(np.float32)))
+
+
+def _worker(rank, world, port, n, r, c, X, order, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgnn_amd.dist import PartitionedAdj
+        padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, "cpu", rank, world,
+                                       local_factory=OracleBlock)
+        Xl = torch.from_numpy(X[padj.row_begin:padj.row_end].copy())
+        Y = padj.propagate(Xl, order)
+        q.put((rank, padj.row_begin, padj.row_end, Y.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,order", [(2, 1), (2, 2), (3, 3)])
+def test_row_partitioned_matches_single(world, order):
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    n, F = 700, 12
+    r, c = symmetric_simple_numpy(n, 4000, seed=3)
+    X = np.random.default_rng(0).standard_normal((n, F)).astype(np.float32)
+    exp = orc.propagate_scipy(__import__("scipy.sparse").sparse.coo_matrix(
+        (np.ones(r.size, np.float32), (r, c)), shape=(n, n)), X, order)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Y = np.zeros_like(exp)
+    covered = np.zeros(n, bool)
+    for rank, r0, r1, y in got:
+        Y[r0:r1] = y
+        assert not covered[r0:r1].any()
+        covered[r0:r1] = True
+    assert covered.all()
+    assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
+
+
+def test_balanced_splits_and_padding():
+    from sgnn_amd.dist import balanced_row_splits, pad_index_map
+    counts = np.array([100, 1, 1, 1, 1, 50, 50, 1, 1, 1])
+    s = balanced_row_splits(counts, 3)
+    assert s[0] == 0 and s[-1] == 10 and all(a <= b for a, b in zip(s, s[1:]))
+    loads = [counts[s[p]:s[p + 1]].sum() for p in range(3)]
+    assert max(loads) <= 110                        # the heavy first row is a block of its own
+    m, max_rows = pad_index_map(s)
+    assert max_rows == max(s[p + 1] - s[p] for p in range(3))
+    assert len(set(m.tolist())) == 10 and m.max() < 3 * max_rows
+    for p in range(3):
+        assert (m[s[p]:s[p + 1]] == p * max_rows + np.arange(s[p + 1] - s[p])).all()
+    assert balanced_row_splits(np.ones(5), 1) == [0, 5]
+    assert balanced_row_splits(np.ones(2), 4)[-1] == 2     # more ranks than rows: empty blocks allowed
