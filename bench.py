@@ -69,7 +69,7 @@ def load_traffic(workload):
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get(workload)
+        return float(d[workload]["hbm_fabric_bytes"])
     except Exception:
         return None
 
@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-degree", type=int, default=None, help="clip hub degree (real Reddit's is ~21.7k)")
+    ap.add_argument("--slices", type=int, default=2,
+                    help="N > 1: feature slices of the exchange/SpMM pipeline (1 = no overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-edges", type=int, default=10_000_000)
     args = ap.parse_args()
@@ -133,9 +135,30 @@ def main():
         nnz = padj.global_nnz
         Xl = X[padj.row_begin:padj.row_end].contiguous()
         del X
-        step = lambda: padj.propagate(Xl, args.order)        # noqa: E731
+        # the overlapped (feature-sliced) schedule is used only if it reproduces the
+        # plain one on this machine; every rank takes the same decision
+        slices = max(1, args.slices)
+        if slices > 1:
+            ok = torch.ones(1, device=device)
+            try:
+                a = padj.propagate(Xl, args.order, slices=1)
+                b = padj.propagate(Xl, args.order, slices=slices)
+                if not torch.allclose(a, b, rtol=1e-4, atol=1e-5):
+                    ok.zero_()
+                del a, b
+            except Exception as exc:          # noqa: BLE001
+                print(f"[rank {rank}] sliced schedule failed: {exc}", file=sys.stderr, flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0:
+                slices = 1
+        extra["exchange_slices"] = slices
+        step = lambda: padj.propagate(Xl, args.order, slices=slices)        # noqa: E731
         max_deg = padj.global_max_degree
 
+    lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
+    R = lib.sgnn_rowgroup_config(F)
+    kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -183,6 +206,7 @@ def main():
                             f"nnz(A+I)={nnz}, F={F}, order={args.order}, max_degree={max_deg}, unit weights",
                 "rows": "one GPU" if world == 1 else f"row-partitioned over {world} GPUs, all-gather of scaled X blocks",
                 "graph_gen_s": round(t_gen, 2),
+                "kernel": kernel_path,
                 **{k: round(v, 2) for k, v in extra.items()},
             },
             "roofline": {
