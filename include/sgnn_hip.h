@@ -79,7 +79,8 @@ size_t sgnn_build_workspace_bytes(int64_t n, int64_t nnz_in);
  *   rowptr     [n+1] int32 out
  *   colidx     [nnz_in + n] int32 out (capacity; *nnz_out entries are valid)
  *   vals       [nnz_in + n] fp32 out
- *   deg        [n] fp32 out: row sums, accumulated in fp32 in column order
+ *   deg        [n] fp32 out: row sums in fp32 (64 strided partial sums folded in halves;
+ *              exact, hence order-free, for integer-valued weights)
  *   dinv       [n] fp32 out: 1.0f / sqrtf(deg) (two roundings, as utils.py:88-89);
  *              with zero_inf != 0 an infinite result is replaced by 0 (gcn_norm)
  *   nnz_out    device int64 out
@@ -167,7 +168,14 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                        of `plan` hold {merged entries, work items, partial
  *                        slots, split groups} — the caller reads them once and
  *                        passes the last three to every SpMM call
- * sgnn_spmm_rowgroup_f32 workspace >= sgnn_spmm_rowgroup_workspace_bytes(slots, R, F)
+ * sgnn_spmm_rowgroup_f32 workspace >= sgnn_spmm_rowgroup_workspace_bytes(slots, R, F).
+ *                        The plan stores the sparsity pattern only.  An adjacency whose
+ *                        off-diagonal entries all carry one weight w_off (Reddit's A + A^T
+ *                        has 2.0, data_loader.py:75) is handled in the epilogue:
+ *                        row i = w_off * (pattern sum) + corr[i] * x'_i with
+ *                        corr[i] = (diagonal value of row i) - w_off where the row stores
+ *                        a diagonal entry, else 0; x'_i is row (i + x_row_offset) of X
+ *                        (times dinv_col).  Unit weights: w_off = 1, corr = NULL.
  * No reference counterpart for the plan itself: the reference keeps only the
  * COO tensor (utils.py:54-62).
  */
@@ -183,6 +191,7 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
                            const void* plan, size_t plan_bytes,
                            int64_t items, int64_t slots, int64_t n_long,
                            const float* dinv_row, const float* dinv_col,
+                           float w_off, const float* corr, int64_t x_row_offset,
                            const float* X, int64_t ldx, float* Y, int64_t ldy,
                            int epilogue, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -96,6 +96,35 @@ SELF_LOOP_ADD = 1       # diag += 1   (utils.py:83-86: adjacency + self_loop)
 SELF_LOOP_REMAINING = 2  # diag = weight of the last existing loop entry, else 1 (PyG add_remaining_self_loops)
 
 
+def degree_wave_order(rowptr, vals):
+    """fp32 row sums in the order the device kernel uses (it is a parallel
+    reduction, so "column order" is not available there): 64 strided partial sums
+    — partial l adds entries l, l+64, ... of the row in that order — folded in
+    halves (32, 16, ..., 1).  For integer-valued weights every order gives the
+    same fp32 result; for arbitrary weights this is the order that is bit-exact.
+    """
+    n = len(rowptr) - 1
+    lens = np.diff(rowptr)
+    deg = np.zeros(n, dtype=np.float32)
+    exact = vals.size == 0 or (np.all(vals == np.round(vals)) and np.abs(vals).sum(dtype=np.float64) < 2 ** 24)
+    if exact:                                    # order-independent: take the fast path
+        np.add.at(deg, np.repeat(np.arange(n), lens), vals)
+        return deg
+    for r in range(n):
+        v = vals[rowptr[r]:rowptr[r + 1]]
+        steps = -(-v.size // 64)
+        p = np.zeros(steps * 64, dtype=np.float32)
+        p[:v.size] = v
+        lanes = np.zeros(64, dtype=np.float32)
+        for row64 in p.reshape(steps, 64):       # sequential per lane
+            lanes = lanes + row64
+        while lanes.size > 1:
+            h = lanes.size // 2
+            lanes = lanes[:h] + lanes[h:]
+        deg[r] = lanes[0]
+    return deg
+
+
 def norm_csr(row, col, val, n, strip_diag=False, self_loops=SELF_LOOP_ADD, drop_zeros=False):
     """Canonical CSR of the matrix the hot path multiplies by, plus its degree.
 
@@ -107,7 +136,7 @@ def norm_csr(row, col, val, n, strip_diag=False, self_loops=SELF_LOOP_ADD, drop_
 
     Returns ``rowptr[int32 n+1], colidx[int32 nnz], vals[fp32 nnz],
     deg[fp32 n], dinv[fp32 n]`` where ``deg`` is the weighted ROW sum
-    (utils.py:88) accumulated in fp32 in column order, and
+    (utils.py:88) accumulated in fp32 (order: ``degree_wave_order``), and
     ``dinv = 1/sqrt(deg)`` in two roundings (utils.py:88-89).
     """
     row = np.asarray(row, dtype=np.int64)
@@ -162,8 +191,7 @@ def norm_csr(row, col, val, n, strip_diag=False, self_loops=SELF_LOOP_ADD, drop_
     counts = np.bincount(urow, minlength=n)
     rowptr = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(counts, out=rowptr[1:])
-    deg = np.zeros(n, dtype=np.float32)
-    np.add.at(deg, urow, uval)          # fp32, sequential in column order
+    deg = degree_wave_order(rowptr, uval.astype(np.float32))
     with np.errstate(divide="ignore", invalid="ignore"):
         dinv = (np.float32(1.0) / np.sqrt(deg)).astype(np.float32)
     return (rowptr.astype(np.int32), ucol.astype(np.int32), uval.astype(np.float32), deg, dinv)

@@ -45,7 +45,8 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "sgnn_spmm_rowgroup_workspace_bytes": (c_size_t, [c_int64, c_int, c_int64]),
     "sgnn_spmm_rowgroup_f32": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t,
-                                       c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                       ctypes.c_float, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
 }

@@ -144,16 +144,27 @@ __global__ void k_rowptr(int64_t n, int64_t m, const uint32_t* __restrict__ keep
   if (j == total) nnz_out[0] = flag[0] ? -1 : total;
 }
 
-__global__ void k_degree(int64_t n, const int32_t* __restrict__ rowptr, const float* __restrict__ vals, int zero_inf,
-                         float* __restrict__ deg, float* __restrict__ dinv) {
-  int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+// Weighted row degree and dinv, one wavefront per row.  Summation order (fixed, so
+// the result is reproducible and a CPU restatement can match it bit for bit for
+// any weights): lane l adds entries l, l+64, l+128, ... of the row in that order,
+// then the 64 lane sums are folded in halves (lane i += lane i+32, then +16, ... +1).
+__global__ __launch_bounds__(256) void k_degree(int64_t n, const int32_t* __restrict__ rowptr,
+                                                const float* __restrict__ vals, int zero_inf,
+                                                float* __restrict__ deg, float* __restrict__ dinv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = blockIdx.x * int64_t(blockDim.x / 64) + threadIdx.x / 64;
   if (r >= n) return;
+  const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
   float s = 0.0f;
-  for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) s += vals[e];
-  deg[r] = s;
-  float d = 1.0f / sqrtf(s);
-  if (zero_inf && isinf(d)) d = 0.0f;
-  dinv[r] = d;
+  for (int32_t e = e0 + lane; e < e1; e += 64) s += vals[e];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) {
+    deg[r] = s;
+    float d = 1.0f / sqrtf(s);
+    if (zero_inf && isinf(d)) d = 0.0f;
+    dinv[r] = d;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -221,7 +232,7 @@ int sgnn_build_norm_csr(int64_t n, int64_t nnz_in, const int64_t* row, const int
   if (m == 0) {
     HIP_TRY(hipMemsetAsync(rowptr, 0, size_t(n + 1) * 4, st));
     HIP_TRY(hipMemsetAsync(nnz_out, 0, 8, st));
-    hipLaunchKernelGGL(k_degree, dim3(unsigned((n + T - 1) / T)), dim3(T), 0, st, n, rowptr, vals, zero_inf, deg, dinv);
+    hipLaunchKernelGGL(k_degree, dim3(unsigned((n + 3) / 4)), dim3(256), 0, st, n, rowptr, vals, zero_inf, deg, dinv);
     HIP_TRY(hipGetLastError());
     return SGNN_OK;
   }
@@ -243,7 +254,7 @@ int sgnn_build_norm_csr(int64_t n, int64_t nnz_in, const int64_t* row, const int
   hipLaunchKernelGGL(k_rowptr, dim3(unsigned((m + 1 + T - 1) / T)), dim3(T), 0, st, n, m, w.keep, w.pos, w.orow,
                      w.flag, rowptr, nnz_out);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_degree, dim3(unsigned((n + T - 1) / T)), dim3(T), 0, st, n, rowptr, vals, zero_inf, deg, dinv);
+  hipLaunchKernelGGL(k_degree, dim3(unsigned((n + 3) / 4)), dim3(256), 0, st, n, rowptr, vals, zero_inf, deg, dinv);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }

@@ -229,9 +229,10 @@ struct RgArgs {
   const int32_t *grows, *gptr, *gcol;
   const uint32_t* gmask;
   const int32_t *item_group, *item_m0, *item_m1, *item_out, *long_group, *long_slot;
-  const float *dinv_row, *dinv_col, *X;
+  const float *dinv_row, *dinv_col, *X, *corr;
   float *Y, *partial;
-  int64_t ldx, ldy, x_bytes;
+  int64_t ldx, ldy, x_bytes, x_row_offset;
+  float w_off;
   int32_t items, n_long, F, row_bytes, y_vec, epilogue, seg;
 };
 
@@ -269,6 +270,28 @@ __device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, int32_t col
             else acc[r][c][v] += xv[u][c][v];
           }
       }
+}
+
+// Row epilogue.  `s` is the pattern sum (every stored entry counted once).  For an
+// adjacency whose off-diagonal entries all carry the weight w_off and whose
+// diagonal entry of row i is d_i, the weighted sum is w_off*s + (d_i - w_off)*x'_i
+// (corr[i] = d_i - w_off, x' = the scaled row of X the kernel saw); unit-weight
+// graphs have w_off = 1 and corr = NULL.  Then the row scaling of utils.py:95.
+__device__ __forceinline__ float rg_epilogue(const RgArgs& a, float s, int row, int f, bool scale, float dr) {
+  float y = s;
+  if (a.corr != nullptr) {
+    const int64_t xr = int64_t(row) + a.x_row_offset;
+    float xs = a.X[xr * a.ldx + f];
+    if (a.dinv_col != nullptr) xs *= a.dinv_col[xr];
+    y = fmaf(a.w_off, y, a.corr[row] * xs);
+  } else if (a.w_off != 1.0f) {
+    y *= a.w_off;
+  }
+  if (scale) {
+    y = y * dr;
+    if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+  }
+  return y;
 }
 
 // One wavefront per work item; lane l owns features (c*64 + l)*V .. +V of all R
@@ -349,14 +372,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
       if (f < a.F) {
         float o[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          float y = acc[r][c][v];
-          if (scale) {
-            y = y * dr;
-            if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
-          }
-          o[v] = y;
-        }
+        for (int v = 0; v < V; ++v)
+          o[v] = out < 0 ? rg_epilogue(a, acc[r][c][v], row, f + v, scale, dr) : acc[r][c][v];
         store_vec<V>(dst + f, o, aligned_for);
       }
     }
@@ -380,10 +397,7 @@ __global__ void k_rg_combine(RgArgs a) {
   for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
     float s = 0.0f;
     for (int k = 0; k < nseg; ++k) s += a.partial[(int64_t(slot + k) * R + r) * a.F + f];
-    if (scale) {
-      s = s * dr;
-      if (a.epilogue == SGNN_EPI_SCALE_ROW2) s = s * dr;
-    }
+    s = rg_epilogue(a, s, row, f, scale, dr);
     a.Y[int64_t(row) * a.ldy + f] = s;
   }
 }
@@ -529,7 +543,8 @@ size_t sgnn_spmm_rowgroup_workspace_bytes(int64_t slots, int R, int64_t F) {
 
 int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, int R, const void* plan,
                            size_t plan_bytes, int64_t items, int64_t slots, int64_t n_long, const float* dinv_row,
-                           const float* dinv_col, const float* X, int64_t ldx, float* Y, int64_t ldy, int epilogue,
+                           const float* dinv_col, float w_off, const float* corr, int64_t x_row_offset,
+                           const float* X, int64_t ldx, float* Y, int64_t ldy, int epilogue,
                            void* workspace, size_t workspace_bytes, void* stream) {
   if (n_rows <= 0 || n_cols <= 0 || nnz <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty problem");
   if (!plan || !X || !Y) return fail(SGNN_ERR_INVALID, "null pointer");
@@ -551,6 +566,9 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   a.item_group = p.item_group; a.item_m0 = p.item_m0; a.item_m1 = p.item_m1; a.item_out = p.item_out;
   a.long_group = p.long_group; a.long_slot = p.long_slot;
   a.dinv_row = dinv_row; a.dinv_col = dinv_col; a.X = X; a.Y = Y; a.partial = static_cast<float*>(workspace);
+  a.w_off = w_off; a.corr = corr; a.x_row_offset = x_row_offset;
+  if (corr && (x_row_offset < 0 || x_row_offset + n_rows > n_cols))
+    return fail(SGNN_ERR_INVALID, "x_row_offset places the block's own rows outside X");
   a.ldx = ldx; a.ldy = ldy; a.x_bytes = ((n_cols - 1) * ldx + F) * 4;
   a.items = int32_t(items); a.n_long = int32_t(n_long); a.F = int32_t(F);
   a.row_bytes = a.x_bytes < (int64_t(1) << 32) ? int32_t(ldx * 4) : 0;

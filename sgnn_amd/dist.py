@@ -200,10 +200,11 @@ class PartitionedAdj:
 class _LocalBlock:
     """Device CSR of one row block over the padded column space."""
 
-    def __init__(self, adj, dinv_local, n_rows, n_cols_padded):
+    def __init__(self, adj, dinv_local, n_rows, n_cols_padded, x_row_offset):
         self.adj = adj                  # NormAdj whose rows are the local rows (square trick, see build)
         self.dinv = dinv_local
         self.n_rows, self.n_cols = n_rows, n_cols_padded
+        self.x_row_offset = int(x_row_offset)   # where the block's own rows sit in the gathered X
         self._plans = {}
         self._ws = {}
 
@@ -220,9 +221,12 @@ class _LocalBlock:
         pm = torch.from_numpy(padmap).to(device)
         colidx = pm[full.colidx[e0:e1].long()].to(torch.int32).contiguous()
         vals = full.vals[e0:e1].contiguous()
+        # weight structure of the local rows only (the other rows of `full` hold just their self-loop)
+        from .norm_adj import weight_structure
+        unit, w_off, corr = weight_structure(r1 - r0, rowptr, full.colidx[e0:e1] - r0, vals)
         block = NormAdj(r1 - r0, rowptr, colidx, vals, full.deg[r0:r1].contiguous(), full.dinv[r0:r1].contiguous(),
-                        unit_weights=full.unit_weights)
-        return cls(block, block.dinv, r1 - r0, n_cols_padded)
+                        unit_weights=unit, w_off=w_off, corr=corr)
+        return cls(block, block.dinv, r1 - r0, n_cols_padded, int(padmap[r0]) if r1 > r0 else 0)
 
     def scale_rows_into(self, src, dst):
         lib = _lib.load()
@@ -232,7 +236,7 @@ class _LocalBlock:
 
     def _plan(self, F):
         a = self.adj
-        if not a.unit_weights or a.nnz == 0:
+        if a.w_off is None or a.nnz == 0:
             return None
         lib = _lib.load()
         R = lib.sgnn_rowgroup_config(F)
@@ -270,6 +274,7 @@ class _LocalBlock:
             _lib.check(lib.sgnn_spmm_rowgroup_f32(
                 self.n_rows, self.n_cols, a.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
                 plan["items"], plan["slots"], plan["n_long"], _lib.ptr(self.dinv), None,
+                float(a.w_off), _lib.ptr(a.corr), self.x_row_offset,
                 _lib.ptr(full), full.stride(0), _lib.ptr(out), out.stride(0), epi, _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(dev)))
             return

@@ -24,6 +24,37 @@ def _as_index_tensor(a, device):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int64))).to(device)
 
 
+def weight_structure(n, rowptr, colidx, vals):
+    """Classify the stored values of ``A (+ I)``.
+
+    Returns ``(unit, w_off, corr)``: ``unit`` — every value is 1; ``w_off`` — the
+    common value of all off-diagonal entries, or None if they differ (Reddit's
+    ``A + A^T`` is 2.0 everywhere, data_loader.py:75); ``corr`` — per row,
+    ``diagonal value - w_off`` where the row stores a diagonal entry, else 0
+    (None when that is zero everywhere).  With these the weighted row sum is
+    ``w_off * (pattern sum) + corr_i * x_i``, which is what lets a pattern-only
+    kernel serve such graphs.
+    """
+    total = int(colidx.numel())
+    if total == 0 or bool((vals == 1.0).all().item()):
+        return True, 1.0, None
+    counts = (rowptr[1:] - rowptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=vals.device), counts)
+    diag = rows == colidx.long()
+    off = vals[~diag]
+    if off.numel() == 0:
+        w = 1.0
+    else:
+        w = float(off[0].item())
+        if not bool((off == w).all().item()):
+            return False, None, None
+    corr = torch.zeros(n, dtype=torch.float32, device=vals.device)
+    corr[rows[diag]] = vals[diag] - w
+    if not bool((corr != 0).any().item()):
+        corr = None
+    return False, w, corr
+
+
 def _require_gpu(device):
     device = torch.device(device)
     if device.type != "cuda":
@@ -39,18 +70,23 @@ def _require_gpu(device):
 class NormAdj:
     """CSR of ``A (+ I)`` with degree vectors, resident on one GPU."""
 
-    def __init__(self, n, rowptr, colidx, vals, deg, dinv, unit_weights=False, symmetric=None):
+    def __init__(self, n, rowptr, colidx, vals, deg, dinv, unit_weights=False, symmetric=None,
+                 w_off=None, corr=None):
         self.n = int(n)
         self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
         self.deg, self.dinv = deg, dinv
         self.nnz = int(colidx.numel())
         self.unit_weights = bool(unit_weights)
+        # uniform off-diagonal weight (None: weights vary) and per-row diagonal
+        # correction for the pattern-only row-group kernel, see weight_structure()
+        self.w_off = 1.0 if unit_weights else w_off
+        self.corr = None if unit_weights else corr
         self.device = rowptr.device
         self._symmetric = symmetric
         self._transposed = None
         self._ws = {}
         self._plans = {}                  # R -> row-group plan (built on first use)
-        self.use_rowgroup = True          # unit-weight graphs, supported widths: see _rowgroup_plan
+        self.use_rowgroup = True          # uniform-weight graphs, supported widths: see _rowgroup_plan
 
     # the reference's callers only ever look at .shape[0] of the adjacency handle
     # (model/SGNN.py:33)
@@ -103,8 +139,8 @@ class NormAdj:
                 raise ValueError(f"adjacency indices out of range for a {n} x {n} matrix")
             colidx = colidx[:total].clone()
             vals = vals[:total].clone()
-            unit = bool((vals == 1.0).all().item()) if total else True
-        return cls(n, rowptr, colidx, vals, deg, dinv, unit_weights=unit)
+            unit, w_off, corr = weight_structure(n, rowptr, colidx, vals)
+        return cls(n, rowptr, colidx, vals, deg, dinv, unit_weights=unit, w_off=w_off, corr=corr)
 
     @classmethod
     def from_scipy(cls, mat, device, **kw):
@@ -148,8 +184,8 @@ class NormAdj:
 
     def _rowgroup_plan(self, F):
         """Row-group plan for feature width F, or None when the plain CSR kernel
-        must be used (weighted adjacency, unsupported width, switched off)."""
-        if not (self.use_rowgroup and self.unit_weights) or self.nnz == 0:
+        must be used (off-diagonal weights differ, unsupported width, switched off)."""
+        if not self.use_rowgroup or self.w_off is None or self.nnz == 0:
             return None
         lib = _lib.load()
         R = lib.sgnn_rowgroup_config(F)
@@ -192,6 +228,7 @@ class NormAdj:
                 self.n, self.n, self.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
                 plan["items"], plan["slots"], plan["n_long"],
                 dinv if scale_rows else None, dinv if scale_cols else None,
+                float(self.w_off), _lib.ptr(self.corr), 0,
                 _lib.ptr(X), ldx, _lib.ptr(Y), ldy, int(epilogue), _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(self.device)))
             return
@@ -288,7 +325,7 @@ class NormAdj:
             self._transposed = self
         else:
             t = NormAdj(self.n, t_rowptr, t_colidx, t_vals, self.deg, self.dinv,
-                        unit_weights=self.unit_weights, symmetric=False)
+                        unit_weights=self.unit_weights, symmetric=False, w_off=self.w_off, corr=self.corr)
             t._transposed = self
             t.use_rowgroup = self.use_rowgroup
             self._transposed = t

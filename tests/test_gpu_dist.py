@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, r, c, X, order, slices, q):
+def _worker(rank, world, port, n, r, c, X, order, slices, q, w=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -26,7 +26,8 @@ def _worker(rank, world, port, n, r, c, X, order, slices, q):
     try:
         from sgnn_amd.dist import PartitionedAdj
         dev = torch.device("cuda:0")
-        padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, dev, rank, world)
+        val = None if w is None else torch.full((r.size,), w, dtype=torch.float32)
+        padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), val, n, dev, rank, world)
         Xl = torch.from_numpy(X[padj.row_begin:padj.row_end].copy()).to(dev)
         Y = padj.propagate(Xl, order, slices=slices)
         torch.cuda.synchronize()
@@ -36,20 +37,21 @@ def _worker(rank, world, port, n, r, c, X, order, slices, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("F,order,slices", [(96, 1, 1), (602, 2, 1), (602, 2, 2), (7, 2, 1)])
-def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices):
+@pytest.mark.parametrize("F,order,slices,w", [(96, 1, 1, None), (602, 2, 1, None), (602, 2, 2, None), (7, 2, 1, None),
+                                              (128, 2, 1, 2.0)])
+def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w):
     from sgnn_amd import NormAdj
     from sgnn_amd.graphgen import symmetric_simple_numpy
     n = 20_000
     r, c = symmetric_simple_numpy(n, 300_000, seed=4)
     X = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
-    adj = NormAdj.from_coo(r, c, None, n, gpu_device)
+    adj = NormAdj.from_coo(r, c, None if w is None else np.full(r.size, w, np.float32), n, gpu_device)
     exp = adj.propagate(torch.from_numpy(X).to(gpu_device), order).cpu().numpy()
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, slices, q)) for k in range(world)]
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, slices, q, w)) for k in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]

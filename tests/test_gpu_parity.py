@@ -162,11 +162,14 @@ def test_propagate_wide_weight2_vs_reference(dev):
     g = load_golden("rmat512_f602_w2.npz")
     n = int(g["n"])
     adj = _na().from_coo(g["row"], g["col"], g["val"], n, dev)
-    assert not adj.unit_weights
+    assert not adj.unit_weights and adj.w_off == 2.0 and adj.corr is not None      # off-diagonal 2, diagonal 1
     X = hashed_features(n, 602, seed=602)
-    Y = adj.propagate(torch.from_numpy(X).to(dev), 1)
     rowptr, colidx, vals, deg, dinv = orc.norm_csr(g["row"], g["col"], g["val"], n)
-    _check_Y(Y, g["Y_F602_o1"], rowptr, colidx, vals, dinv, X, 1)
+    for flag in (True, False):                      # pattern-only row-group kernel, then plain CSR with values
+        adj.use_rowgroup = flag
+        assert (adj._rowgroup_plan(602) is not None) == flag
+        Y = adj.propagate(torch.from_numpy(X).to(dev), 1)
+        _check_Y(Y, g["Y_F602_o1"], rowptr, colidx, vals, dinv, X, 1)
 
 
 def test_propagate_directed_raw_vs_reference(dev):
@@ -185,6 +188,49 @@ def test_propagate_directed_raw_vs_reference(dev):
     adj = _na().from_coo(r, c, v, n, dev, strip_diag=True, drop_zeros=True)
     rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n, strip_diag=True, drop_zeros=True)
     _check_Y(adj.propagate(torch.from_numpy(X).to(dev), 1), g["Y_strip_o1"], rowptr, colidx, vals, dinv, X, 1)
+
+
+@pytest.mark.parametrize("w", [2.0, 0.3])
+def test_uniform_weight_graph_with_stored_diagonal(dev, w):
+    """Off-diagonal entries all w, some rows with their own diagonal entry (value 5),
+    an isolated node, no self-loops added: the pattern kernel's diagonal correction."""
+    from sgnn_amd import _lib
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    n, F = 3000, 96
+    r, c = symmetric_simple_numpy(n - 1, 20_000, seed=12)          # node n-1 stays isolated
+    d = np.arange(0, n, 7)
+    r2, c2 = np.concatenate((r, d)), np.concatenate((c, d))
+    v = np.concatenate((np.full(r.size, w, np.float32), np.full(d.size, 5.0, np.float32)))
+    X = np.random.default_rng(3).standard_normal((n, F)).astype(np.float32)
+    for loops in (_lib.LOOPS_ADD, _lib.LOOPS_NONE):
+        adj = _na().from_coo(r2, c2, v, n, dev, self_loops=loops, zero_inf=True)
+        assert adj.w_off == np.float32(w) and adj.corr is not None
+        rowptr, colidx, vals, deg, dinv = orc.norm_csr(r2, c2, v, n, self_loops=loops)
+        dinv = np.where(np.isinf(dinv), np.float32(0), dinv)
+        assert np.array_equal(adj.dinv.cpu().numpy(), dinv)
+        exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, X))
+        for flag in (True, False):
+            adj.use_rowgroup = flag
+            _check_Y(adj.propagate(torch.from_numpy(X).to(dev), 2), exp, rowptr, colidx, vals, dinv, X, 2)
+
+
+def test_degree_bit_exact_for_fractional_weights(dev):
+    """The degree is a parallel fp32 reduction in a fixed order; the oracle follows
+    the same order, so even non-integer weights give identical bits."""
+    n = 2000
+    r, c = _hub_graph(n, seed=5)
+    key = np.unique(r.astype(np.int64) * n + c)
+    r, c = key // n, key % n
+    v = np.random.default_rng(9).uniform(0.1, 3.0, r.size).astype(np.float32)
+    adj = _na().from_coo(r, c, v, n, dev)
+    assert adj.w_off is None
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
+    assert np.array_equal(adj.vals.cpu().numpy(), vals)
+    assert np.array_equal(adj.deg.cpu().numpy(), deg)
+    assert np.array_equal(adj.dinv.cpu().numpy(), dinv)
+    X = np.random.default_rng(1).standard_normal((n, 40)).astype(np.float32)
+    _check_Y(adj.propagate(torch.from_numpy(X).to(dev), 1), orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, X),
+             rowptr, colidx, vals, dinv, X, 1)
 
 
 def _hub_graph(n, seed):
