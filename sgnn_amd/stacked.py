@@ -1,0 +1,219 @@
+"""Decoupled stacked-GNN training on top of the propagation boundary.
+
+This is the caller side of the hot path: the supervised stacked model of the
+reference (``SupervisedStackedGNN`` with embedding-GCN layers, the only layer
+type its classification runner builds — GNN_tasks.py:76-87) restated in plain
+PyTorch so that the end-to-end accuracy of the reference can be reproduced above
+``sgnn_amd.utils``.  The numerics that matter for parity follow the reference:
+
+* a layer is ``act(inner_act(X' U) W)`` with ``X' = A_hat^order X``
+  (model/SGNN.py:73-78, 404-405), ``U`` starting at the identity;
+* forward sweeps train ``W`` (and the label head ``Wt``) with ``U`` frozen,
+  backward sweeps also train ``U`` of every layer but the first
+  (model/SGNN.py:567-600), targets being the next layer's expected input
+  ``X U`` (model/SGNN.py:442, 576-578, 599);
+* losses: cross-entropy through ``Wt`` without a target, ``eta * ||E - T||_F^2 / m``
+  with one (model/SGNN.py:80-86, 388-399), a second target term on a batch drawn
+  from all nodes (model/SGNN.py:425-429), ridge penalty ``lam * (|W|^2+|b|^2+|U|^2)``
+  (model/SGNN.py:88-92), a fresh Adam per ``run`` (model/SGNN.py:417), batches drawn
+  as the head of a random permutation (model/SGNN.py:115-117).
+
+What differs, on purpose (these are the residency items the reference leaves on
+the table): features, targets and embeddings stay on the GPU instead of bouncing
+through host memory on every call (model/SGNN.py:404, 442-443), and ``A_hat^k X`` of a
+layer is computed once per distinct input instead of on every ``run`` — the first
+layer's input never changes, so 2*BP_count of its 2*BP_count+1 propagations
+disappear.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+from . import utils as prop
+
+
+class Func(torch.nn.Module):
+    """Activation wrapper with the reference's signature (model/SGNN.py:706-713)."""
+
+    def __init__(self, func, **params):
+        super().__init__()
+        self.func, self.params = func, params
+
+    def forward(self, X):
+        return X if self.func is None else self.func(X, **self.params)
+
+
+def get_activation(spec):
+    """Activation strings of the reference's configs (GNN_tasks.py:387-404)."""
+    if "tanh" in spec:
+        return Func(torch.tanh)
+    if "sigmoid" in spec:
+        return Func(torch.sigmoid)
+    if "linear" in spec:
+        return Func(None)
+    if "leaky" in spec:
+        return Func(Fn.leaky_relu, negative_slope=float(spec.split("=")[1]))
+    if spec == "relu":
+        return Func(Fn.relu)
+    raise ValueError(f"unknown activation {spec!r}")
+
+
+class LayerParam:
+    """Per-layer hyper-parameters (model/SGNN.py:729-758)."""
+    GAE, GCN, EGCN = 0, 1, 2
+
+    def __init__(self, neurons, inner_act=None, act=None, gnn_type=EGCN, **kwargs):
+        self.neurons = neurons
+        self.inner_activation = inner_act if inner_act is not None else Func(None)
+        self.activation = act if act is not None else Func(None)
+        self.gnn_type = gnn_type
+        self.extra_params = kwargs
+
+    def get(self, key, default):
+        return self.extra_params.get(key, default)
+
+
+def _glorot(rows, cols, device):
+    bound = math.sqrt(6.0 / (rows + cols))                       # utils.py:65-68
+    return torch.nn.Parameter((torch.rand(rows, cols, device=device) * 2 - 1) * bound)
+
+
+class EmbeddingLayer(torch.nn.Module):
+    """One decoupled layer with a label head (SingleLayerEmbeddingGCN, model/SGNN.py:357-467)."""
+
+    def __init__(self, adjacency, labels, train_mask, input_dim, embedding_dim, n_class, p, device):
+        super().__init__()
+        self.adjacency, self.device = adjacency, device
+        self.order = p.get("order", 1)
+        self.lam = p.get("lam", 0)
+        self.lr = p.get("learning_rate", 0.01)
+        self.max_iter = p.get("max_iter", 10)
+        self.batch_size = p.get("batch_size", 64)
+        self.inner_activation, self.activation = p.inner_activation, p.activation
+        self.W = _glorot(input_dim, embedding_dim, device)
+        self.b = _glorot(1, embedding_dim, device)
+        self.U = torch.nn.Parameter(torch.eye(input_dim, device=device), requires_grad=False)
+        self.Wt = _glorot(embedding_dim, n_class, device)
+        self.labels, self.train_mask = labels, train_mask
+        self.expected_X = None
+        self._cache_in, self._cache_version, self._cache_val = None, -1, None
+
+    def set_training_direction(self, is_backward, reset_backward=True):
+        self.U.requires_grad = is_backward
+        if not is_backward and reset_backward:
+            with torch.no_grad():
+                self.U.copy_(torch.eye(self.U.shape[0], device=self.device))
+
+    def forward(self, X):
+        return self.activation(self.inner_activation(X.matmul(self.U)).matmul(self.W))
+
+    def propagated(self, X):
+        """``A_hat^order X``, recomputed only when the input changes."""
+        # keyed on the tensor object (kept alive here, so its storage cannot be reused
+        # by another tensor) and its in-place version counter
+        if X is not self._cache_in or X._version != self._cache_version:
+            self._cache_val = prop.process_data_with_adjacency_high_order(self.adjacency, X, self.device,
+                                                                          order=self.order)
+            self._cache_in, self._cache_version = X, X._version
+        return self._cache_val
+
+    def _penalty(self):
+        return self.W.pow(2).sum() + self.b.pow(2).sum() + self.U.pow(2).sum()
+
+    def _batch(self, rows):
+        return torch.randperm(rows, device=self.device)[:self.batch_size]
+
+    def run(self, X, embedding_target=None, eta=1, train=True):
+        PX = self.propagated(X)
+        if train:
+            tX = PX[self.train_mask]
+            tT = None if embedding_target is None else embedding_target[self.train_mask]
+            tY = self.labels[self.train_mask]
+            opt = torch.optim.Adam([q for q in self.parameters()], lr=self.lr)
+            for _ in range(self.max_iter):
+                opt.zero_grad()
+                idx = self._batch(tX.shape[0])
+                emb = self(tX[idx])
+                if tT is None:
+                    loss = Fn.cross_entropy(emb.matmul(self.Wt), tY[idx])
+                else:
+                    loss = eta * (emb - tT[idx]).pow(2).sum() / emb.shape[0]
+                loss = loss + self.lam * self._penalty()
+                if embedding_target is not None:
+                    jdx = self._batch(PX.shape[0])
+                    e2 = self(PX[jdx])
+                    loss = loss + eta * (e2 - embedding_target[jdx]).pow(2).sum() / e2.shape[0]
+                loss.backward()
+                opt.step()
+        with torch.no_grad():
+            embedding = self(PX)
+            self.expected_X = X.matmul(self.U)
+        return embedding
+
+    @torch.no_grad()
+    def predict(self, embedding):
+        return embedding.matmul(self.Wt).argmax(dim=1)
+
+
+class SupervisedStackedGNN:
+    """Stack of decoupled layers with forward / backward sweeps
+    (model/SGNN.py:470-600, 628-679).  ``run()`` returns the predicted labels of
+    all nodes as a numpy array."""
+
+    def __init__(self, content, adjacency, layers, training_mask, val_mask=None, labels=None,
+                 overlooked_rates=None, eta=1, BP_count=0, device=None, metric_func=None, logger=None, rank=None):
+        if labels is None:
+            raise ValueError("labels are required")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        A = adjacency.tocsr()
+        A = A - _diag_of(A)                                       # model/SGNN.py:497-501
+        self.adjacency_tensor = prop.csr_to_sparse_Tensor(A, self.device)
+        self.content = torch.as_tensor(np.asarray(content), dtype=torch.float32).to(self.device)
+        self.labels = torch.as_tensor(np.asarray(labels)).long().to(self.device)
+        self.training_mask = torch.as_tensor(np.asarray(training_mask)).to(self.device)
+        self.eta, self.BP_count = eta, int(BP_count)
+        self.metric_func, self.logger = metric_func, logger
+        n_class = int(np.unique(np.asarray(labels)).shape[0])
+        self.gnns = []
+        dim = self.content.shape[1]
+        for p in layers:
+            if p.gnn_type != LayerParam.EGCN:
+                raise NotImplementedError("only embedding-GCN layers (the classification runner's type) are built")
+            self.gnns.append(EmbeddingLayer(self.adjacency_tensor, self.labels, self.training_mask, dim,
+                                            p.neurons, n_class, p, self.device))
+            dim = p.neurons
+
+    def _forward_sweep(self, with_targets):
+        inputs, x = [], self.content
+        for i, g in enumerate(self.gnns):
+            inputs.append(x)
+            target = self.gnns[i + 1].expected_X if with_targets and i + 1 < len(self.gnns) else None
+            g.set_training_direction(False, reset_backward=(i != 0))
+            x = g.run(x, embedding_target=target, eta=self.eta)
+        return inputs, x
+
+    def _backward_sweep(self, inputs):
+        target = None
+        for i in reversed(range(len(self.gnns))):
+            g = self.gnns[i]
+            g.set_training_direction(i != 0)
+            g.run(inputs[i], embedding_target=target, eta=self.eta)
+            target = g.expected_X
+
+    def run(self):
+        inputs, embedding = self._forward_sweep(False)
+        for _ in range(self.BP_count):
+            self._backward_sweep(inputs)
+            inputs, embedding = self._forward_sweep(True)
+        return self.gnns[-1].predict(embedding).cpu().numpy()
+
+
+def _diag_of(A):
+    import scipy.sparse as sp
+    n = A.shape[0]
+    idx = np.arange(n)
+    return sp.coo_matrix((A.diagonal(), (idx, idx)), shape=(n, n)).tocsr()
