@@ -26,6 +26,9 @@ namespace sgnn {
 // records the calling thread's error message and returns `code`
 int fail(int code, const std::string& msg);
 
+// tuning hook: merged columns per row-group work item for plans built afterwards (0 = policy)
+void set_rowgroup_segment(int cols);
+
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \

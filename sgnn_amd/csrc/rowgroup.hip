@@ -29,7 +29,10 @@ constexpr int kWavesPerBlock = 4;
 // length.  A wavefront works through its list serially, so small graphs get short
 // segments (enough wavefronts to hide latency) and large ones long segments
 // (fewer partial rows to combine).
+int g_seg_override = 0;   // sgnn_tune_set("rg_seg", v)
+
 int seg_cols_for(int64_t nnz) {
+  if (g_seg_override > 0) return g_seg_override;
   int seg = 64;
   while (seg < 1024 && nnz / seg > 32768) seg *= 2;
   return seg;
@@ -79,6 +82,8 @@ struct BuildWs {
   uint32_t *head, *pos;
   int32_t* ogroup;
   uint32_t *nseg, *first, *lseg, *slot0, *lflag, *lidx;
+  uint64_t *ikey_a, *ikey_b;   // item ordering
+  int32_t* itmp;               // [4 * cap_items]
   void* prim;
   size_t prim_bytes;
   size_t total;
@@ -104,10 +109,15 @@ BuildWs carve_build(void* base, int64_t n_rows, int64_t nnz, int R) {
   w.slot0 = c.take<uint32_t>(G);
   w.lflag = c.take<uint32_t>(G);
   w.lidx = c.take<uint32_t>(G);
+  const int64_t cap_items = G + nnz / seg_cols_for(nnz) + 1;
+  w.ikey_a = c.take<uint64_t>(cap_items);
+  w.ikey_b = c.take<uint64_t>(cap_items);
+  w.itmp = c.take<int32_t>(4 * cap_items);
   size_t s1 = 0, s2 = 0, s3 = 0;
   uint64_t* k64 = nullptr;
   uint32_t* k32 = nullptr;
-  (void)rocprim::radix_sort_keys(nullptr, s1, k64, k64, size_t(nnz), 0u, 64u, hipStream_t(0));
+  (void)rocprim::radix_sort_keys(nullptr, s1, k64, k64, size_t(nnz > cap_items ? nnz : cap_items), 0u, 64u,
+                                 hipStream_t(0));
   (void)rocprim::radix_sort_pairs(nullptr, s2, k32, k32, k32, k32, size_t(n_rows), 0u, 32u, hipStream_t(0));
   (void)rocprim::exclusive_scan(nullptr, s3, k32, k32, 0u, size_t(nnz > n_rows ? nnz : n_rows),
                                 rocprim::plus<uint32_t>(), hipStream_t(0));
@@ -222,6 +232,40 @@ __global__ void k_items(int64_t G, int kSegCols, const int32_t* __restrict__ gpt
     counts[3] = int64_t(lidx[g]) + (ns > 1 ? 1 : 0);
     counts[4] = kSegCols;
   }
+}
+
+// Order the work items by the column block their merged list starts in (ties: build
+// order).  Wavefronts that run at the same time then walk the same region of X, and
+// most of their row fetches hit the XCD's L2 instead of going to the Infinity Cache.
+constexpr int kOrderCols = 4096;
+
+__global__ void k_item_keys(int64_t cap_items, const int64_t* __restrict__ counts, const int32_t* __restrict__ item_m0,
+                            const int32_t* __restrict__ gcol, uint64_t* __restrict__ keys) {
+  int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (it >= cap_items) return;
+  keys[it] = it < counts[1] ? ((uint64_t(gcol[item_m0[it]] / kOrderCols) << 32) | uint64_t(it)) : ~uint64_t(0);
+}
+
+__global__ void k_item_copy(int64_t cap_items, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                            const int32_t* __restrict__ c, const int32_t* __restrict__ d, int32_t* __restrict__ tmp) {
+  int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (it >= cap_items) return;
+  tmp[it] = a[it];
+  tmp[cap_items + it] = b[it];
+  tmp[2 * cap_items + it] = c[it];
+  tmp[3 * cap_items + it] = d[it];
+}
+
+__global__ void k_item_permute(int64_t cap_items, const int64_t* __restrict__ counts, const uint64_t* __restrict__ keys,
+                               const int32_t* __restrict__ tmp, int32_t* __restrict__ a, int32_t* __restrict__ b,
+                               int32_t* __restrict__ c, int32_t* __restrict__ d) {
+  int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (it >= counts[1]) return;
+  const int64_t src = int64_t(keys[it] & 0xffffffffu);
+  a[it] = tmp[src];
+  b[it] = tmp[cap_items + src];
+  c[it] = tmp[2 * cap_items + src];
+  d[it] = tmp[3 * cap_items + src];
 }
 
 // ---- the kernel ------------------------------------------------------------------
@@ -461,6 +505,10 @@ bool rg_layout(int64_t F, int* V, int* C) {
 
 }  // namespace
 
+namespace sgnn {
+void set_rowgroup_segment(int cols) { g_seg_override = cols; }
+}  // namespace sgnn
+
 extern "C" {
 
 int sgnn_rowgroup_config(int64_t F) {
@@ -532,6 +580,18 @@ int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lflag, w.lidx, 0u, size_t(p.G), rocprim::plus<uint32_t>(), st));
   hipLaunchKernelGGL(k_items, blocks(p.G), dim3(T), 0, st, p.G, seg, p.gptr, w.nseg, w.first, w.slot0, w.lidx,
                      p.item_group, p.item_m0, p.item_m1, p.item_out, p.long_group, p.long_slot, p.counts);
+  HIP_TRY(hipGetLastError());
+  // launch order of the items
+  hipLaunchKernelGGL(k_item_keys, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.counts, p.item_m0, p.gcol,
+                     w.ikey_a);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.ikey_a, w.ikey_b, size_t(p.cap_items), 0u, 64u, st));
+  hipLaunchKernelGGL(k_item_copy, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.item_group, p.item_m0,
+                     p.item_m1, p.item_out, w.itmp);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_item_permute, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.counts, w.ikey_b, w.itmp,
+                     p.item_group, p.item_m0, p.item_m1, p.item_out);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }

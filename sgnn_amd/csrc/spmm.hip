@@ -463,6 +463,7 @@ int sgnn_tune_set(const char* key, int value) {
   if (!key) return fail(SGNN_ERR_INVALID, "null key");
   if (!std::strcmp(key, "tile")) g_tune.tile = value;
   else if (!std::strcmp(key, "unroll")) g_tune.unroll = value;
+  else if (!std::strcmp(key, "rg_seg")) sgnn::set_rowgroup_segment(value);
   else return fail(SGNN_ERR_INVALID, std::string("unknown tuning key ") + key);
   return SGNN_OK;
 }
