@@ -30,6 +30,7 @@ constexpr int kWavesPerBlock = 4;
 // segments (enough wavefronts to hide latency) and large ones long segments
 // (fewer partial rows to combine).
 int g_seg_override = 0;   // sgnn_tune_set("rg_seg", v)
+int g_R_override = 0;     // sgnn_tune_set("rg_R", v)
 
 int seg_cols_for(int64_t nnz) {
   if (g_seg_override > 0) return g_seg_override;
@@ -438,9 +439,21 @@ __global__ void k_rg_combine(RgArgs a) {
   if (row < 0) return;
   const bool scale = a.dinv_row != nullptr;
   const float dr = scale ? a.dinv_row[row] : 1.0f;
+  const int64_t stride = int64_t(R) * a.F;                       // between consecutive segments' partial rows
   for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
-    float s = 0.0f;
-    for (int k = 0; k < nseg; ++k) s += a.partial[(int64_t(slot + k) * R + r) * a.F + f];
+    // four interleaved running sums (segments k, k+4, ...) keep four loads in flight;
+    // they are folded in a fixed order, so the result stays reproducible
+    const float* p = a.partial + (int64_t(slot) * R + r) * a.F + f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int k = 0;
+    for (; k + 4 <= nseg; k += 4) {
+      s0 += p[(k + 0) * stride];
+      s1 += p[(k + 1) * stride];
+      s2 += p[(k + 2) * stride];
+      s3 += p[(k + 3) * stride];
+    }
+    for (; k < nseg; ++k) s0 += p[k * stride];
+    float s = (s0 + s1) + (s2 + s3);
     s = rg_epilogue(a, s, row, f, scale, dr);
     a.Y[int64_t(row) * a.ldy + f] = s;
   }
@@ -507,6 +520,7 @@ bool rg_layout(int64_t F, int* V, int* C) {
 
 namespace sgnn {
 void set_rowgroup_segment(int cols) { g_seg_override = cols; }
+void set_rowgroup_R(int R) { g_R_override = R; }
 }  // namespace sgnn
 
 extern "C" {
@@ -514,6 +528,7 @@ extern "C" {
 int sgnn_rowgroup_config(int64_t F) {
   int V, C;
   if (F < 33 || !rg_layout(F, &V, &C)) return 0;
+  if (g_R_override == 8 || (g_R_override == 16 && V * C <= 10)) return g_R_override;
   return (V * C <= 10) ? (F <= 128 ? 8 : 16) : 8;
 }
 

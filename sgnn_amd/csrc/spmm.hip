@@ -312,12 +312,16 @@ __global__ void k_spmm_combine(SpmmArgs a) {
   }
 }
 
-__global__ void k_row_scale(int64_t n, int64_t F, const float* __restrict__ scale, const float* __restrict__ in,
-                            int64_t ldin, float* __restrict__ out, int64_t ldout) {
-  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-  if (i >= n * F) return;
-  int64_t r = i / F, f = i - r * F;
-  out[r * ldout + f] = in[r * ldin + f] * scale[r];
+// out[r, :] = scale[r] * in[r, :]; one wavefront per row, lanes along the row
+__global__ __launch_bounds__(256) void k_row_scale(int64_t n, int64_t F, const float* __restrict__ scale,
+                                                   const float* __restrict__ in, int64_t ldin,
+                                                   float* __restrict__ out, int64_t ldout) {
+  const int64_t r = blockIdx.x * int64_t(4) + threadIdx.x / kWave;
+  if (r >= n) return;
+  const float s = scale[r];
+  const float* src = in + r * ldin;
+  float* dst = out + r * ldout;
+  for (int64_t f = threadIdx.x & (kWave - 1); f < F; f += kWave) dst[f] = src[f] * s;
 }
 
 struct SpmmWs {
@@ -464,6 +468,7 @@ int sgnn_tune_set(const char* key, int value) {
   if (!std::strcmp(key, "tile")) g_tune.tile = value;
   else if (!std::strcmp(key, "unroll")) g_tune.unroll = value;
   else if (!std::strcmp(key, "rg_seg")) sgnn::set_rowgroup_segment(value);
+  else if (!std::strcmp(key, "rg_R")) sgnn::set_rowgroup_R(value);
   else return fail(SGNN_ERR_INVALID, std::string("unknown tuning key ") + key);
   return SGNN_OK;
 }
@@ -512,8 +517,7 @@ int sgnn_row_scale_f32(int64_t n, int64_t F, const float* scale, const float* in
   if (n < 0 || F < 0) return fail(SGNN_ERR_INVALID, "negative size");
   if (n == 0 || F == 0) return SGNN_OK;
   if (!scale || !in || !out) return fail(SGNN_ERR_INVALID, "null pointer");
-  const int64_t total = n * F;
-  hipLaunchKernelGGL(k_row_scale, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(k_row_scale, dim3(unsigned((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      n, F, scale, in, ldin, out, ldout);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;

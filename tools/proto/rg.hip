@@ -28,7 +28,7 @@ struct RgArgs {
   uint32_t x_bytes;
 };
 
-template <int R, int C, int U>
+template <int R, int C, int U, int ABL>
 __global__ __launch_bounds__(256) void k_rg(RgArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
@@ -64,8 +64,17 @@ __global__ __launch_bounds__(256) void k_rg(RgArgs a) {
         mk[u] = __builtin_amdgcn_readlane(masks, k + u);
         const int soff = col * a.row_bytes;
 #pragma unroll
-        for (int c = 0; c < C; ++c) xv[u][c] = raw_buffer_load_f32x2(rsrc, boff[c], soff, 0);
+        for (int c = 0; c < C; ++c) {
+          if constexpr (ABL == 2) xv[u][c] = f32x2{float(soff), float(boff[c])};
+          else xv[u][c] = raw_buffer_load_f32x2(rsrc, boff[c], soff, 0);
+        }
       }
+      if constexpr (ABL == 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c = 0; c < C; ++c) asm volatile("" ::"v"(xv[u][c]));
+      } else {
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(256) void k_rg(RgArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[r][c] += xv[u][c];
           }
+      }
     }
     for (; k < cnt; ++k) {
       f32x2 xv[C];
@@ -109,25 +119,11 @@ __global__ __launch_bounds__(256) void k_rg(RgArgs a) {
 extern "C" int rg_spmm(int R, int U, RgArgs* a, void* stream) {
   dim3 grid((a->items + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define L(RR, CC, UU) hipLaunchKernelGGL((k_rg<RR, CC, UU>), grid, block, 0, st, *a)
-  int C = (a->F + 127) / 128;
-  if (U >= 10) {   // sliced: U = 10 + slices
-    const int slices = U - 10;
-    grid.y = slices;
-    C = (C + slices - 1) / slices;
-    if (C == 3 && R == 32) L(32, 3, 1); else if (C == 3 && R == 16) L(16, 3, 2); else if (C == 2 && R == 32) L(32, 2, 2);
-    else if (C == 1 && R == 32) L(32, 1, 2);
-    else return -1;
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-  }
-  if (C == 5) {
-    if (R == 8 && U == 2) L(8, 5, 2); else if (R == 8 && U == 1) L(8, 5, 1);
-    else if (R == 16 && U == 1) L(16, 5, 1); else if (R == 16 && U == 2) L(16, 5, 2);
-    else return -1;
-  } else if (C == 1) {
-    if (R == 8 && U == 2) L(8, 1, 2); else if (R == 16 && U == 2) L(16, 1, 2); else if (R == 32 && U == 2) L(32, 1, 2);
-    else if (R == 32 && U == 4) L(32, 1, 4); else if (R == 16 && U == 4) L(16, 1, 4);
-    else return -1;
-  } else return -1;
+  const int C = (a->F + 127) / 128;
+  const int abl = U / 100; U %= 100;
+#define L(RR, CC, UU, AA) hipLaunchKernelGGL((k_rg<RR, CC, UU, AA>), grid, block, 0, st, *a)
+  if (C == 5 && R == 16 && U == 2) { if (abl == 0) L(16, 5, 2, 0); else if (abl == 1) L(16, 5, 2, 1); else L(16, 5, 2, 2); }
+  else if (C == 1 && R == 8 && U == 8) { if (abl == 0) L(8, 1, 8, 0); else if (abl == 1) L(8, 1, 8, 1); else L(8, 1, 8, 2); }
+  else return -1;
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -60,6 +60,45 @@ def build_groups(adj, R, seg, sort_by_degree=True):
                 item_out=item_out.int(), nslots=int(multi.sum()), nseg=nseg, first=first, G=G)
 
 
+def column_aligned_items(g, n, R, target=768, wmin=1024, cap=1536):
+    """Re-cut every group's merged list at column boundaries that are aligned
+    across groups: group g uses blocks of width wmin * 2^j columns, j chosen so a
+    block holds about `target` merged columns; blocks longer than `cap` are split
+    by count."""
+    dev = g["gcol"].device
+    gcol = g["gcol"].long()
+    G = g["G"]
+    gptr = torch.zeros(G + 1, dtype=torch.long, device=dev)
+    # recover gptr from the original (unsplit) items: m0 of first item / m1 of last item per group
+    ig = g["item_group"].long()
+    gptr[1:] = torch.zeros(G, dtype=torch.long, device=dev).scatter_reduce(0, ig, g["m1"].long(), reduce="amax")
+    glen = gptr[1:] - gptr[:-1]
+    width = torch.full((G,), wmin, dtype=torch.long, device=dev)
+    for _ in range(12):
+        width = torch.where(glen.float() * width.float() / n < target, width * 2, width)
+    gid = torch.repeat_interleave(torch.arange(G, device=dev), glen)
+    blk = gcol // width[gid]
+    key = gid * (n + 1) + blk
+    ukey, counts = torch.unique_consecutive(key, return_counts=True)
+    start = torch.cumsum(counts, 0) - counts
+    # split long blocks by count
+    nsub = (counts + cap - 1) // cap
+    sub_item = torch.repeat_interleave(torch.arange(ukey.numel(), device=dev), nsub)
+    firstsub = torch.cumsum(nsub, 0) - nsub
+    ksub = torch.arange(sub_item.numel(), device=dev) - firstsub[sub_item]
+    per = (counts[sub_item] + nsub[sub_item] - 1) // nsub[sub_item]
+    m0 = start[sub_item] + ksub * per
+    m1 = torch.minimum(m0 + per, start[sub_item] + counts[sub_item])
+    item_group = (ukey // (n + 1))[sub_item]
+    nper_group = torch.bincount(item_group, minlength=G)
+    multi = nper_group[item_group] > 1
+    slot = torch.cumsum(multi.long(), 0) - 1
+    item_out = torch.where(multi, slot, torch.full_like(slot, -1))
+    out = dict(g)
+    out.update(item_group=item_group.int(), m0=m0.int(), m1=m1.int(), item_out=item_out.int(), nslots=int(multi.sum()))
+    return out
+
+
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "reddit"
     maxdeg = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
@@ -82,10 +121,17 @@ def main():
     deg = adj.rowptr[1:] - adj.rowptr[:-1]
     print(f"{wl} n={n} nnz={adj.nnz} F={F} max_deg={int(deg.max())}: plain CSR kernel {e0.elapsed_time(e1)/3:.3f} ms", flush=True)
     Xs = (X * adj.dinv[:, None]).contiguous()
-    cfgs = ((16, 2, 1024, True), (16, 12, 1024, True), (32, 12, 1024, True), (32, 13, 1024, True), (32, 15, 1024, True)) if F > 128 else \
-           ((8, 2, 1024, True), (16, 2, 1024, True), (16, 4, 1024, True), (32, 2, 1024, True), (32, 4, 1024, True), (32, 2, 1024, False))
+    cfgs = ((16, 2, 1024, True), (16, 102, 1024, True), (16, 202, 1024, True)) if F > 128 else \
+           ((8, 8, 1024, True), (8, 108, 1024, True), (8, 208, 1024, True))
     for R, U, seg, sortdeg in cfgs:
         g = build_groups(adj, R, seg, sortdeg)
+        if os.environ.get("ALIGNED"):
+            tgt, wmin, cap = (int(v) for v in os.environ["ALIGNED"].split(","))
+            g = column_aligned_items(g, n, R, tgt, wmin, cap)
+        c0 = g["gcol"][g["m0"].long()].long() // int(os.environ.get("ORDERCOLS", "4096"))
+        perm = torch.argsort(c0 * (g["G"] + 1) + g["item_group"].long(), stable=True)
+        for kk in ("item_group", "m0", "m1", "item_out"):
+            g[kk] = g[kk][perm].contiguous()
         Y = torch.zeros(n, F, device=dev)
         partial = torch.zeros(max(g["nslots"], 1) * R * F, device=dev)
         a = RgArgs()
@@ -109,7 +155,7 @@ def main():
             Yp.index_add_(0, rowsel[valid], P[io[sel]][valid])
             long_rows = torch.unique(rowsel[valid])
             Y[long_rows] = Yp[long_rows] * adj.dinv[long_rows, None]
-        err = float((Y - ref).norm() / ref.norm())
+        err = float((Y - ref).norm() / ref.norm()) if U < 100 else float("nan")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
