@@ -105,8 +105,8 @@ class PartitionedAdj:
             self._gather = {key: b}
         return b
 
-    def _all_gather(self, full, piece):
-        if self.world == 1:
+    def _all_gather(self, full, piece, force=False):
+        if self.world == 1 and not force:
             return
         if piece.is_cuda and dist.get_backend(self.group) == "gloo":
             # gloo has no GPU all-gather: stage through the host (several ranks sharing

@@ -62,3 +62,43 @@ def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w):
     for rank, r0, r1, y in got:
         Y[r0:r1] = y
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
+
+
+def _nccl_single(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from sgnn_amd.dist import PartitionedAdj
+        from sgnn_amd.graphgen import symmetric_simple_numpy
+        n = 5000
+        r, c = symmetric_simple_numpy(n, 40_000, seed=8)
+        padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, dev, 0, 1)
+        X = torch.randn(n, 64, device=dev)
+        full = torch.zeros(padj.max_rows, 64, device=dev)
+        full.copy_(X)
+        padj._all_gather(full, full[0:padj.max_rows], force=True)      # RCCL, in place, one rank
+        torch.cuda.synchronize()
+        same = bool(torch.equal(full, X))
+        Y1 = padj.propagate(X, 2)
+        Y2 = padj.propagate(X, 2, slices=2)
+        torch.cuda.synchronize()
+        q.put((same, float((Y1 - Y2).abs().max()), float(Y1.abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank(gpu_device):
+    """The production backend ("nccl" = RCCL) accepts the in-place all-gather the
+    partitioned path issues, and the sliced schedule equals the plain one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single, args=(_free_port(), q))
+    p.start()
+    same, diff, scale = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same
+    assert diff <= 1e-5 * scale
