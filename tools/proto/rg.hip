@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void k_rg(RgArgs a) {
   if (item >= a.items) return;
   const int g = a.item_group[item];
   const int m0 = a.item_m0[item], m1 = a.item_m1[item];
+  if (a.item_out[item] == -2) return;
   const i32x4 rsrc = make_rsrc(a.X, a.x_bytes);
   int boff[C];
 #pragma unroll

@@ -132,6 +132,31 @@ def main():
         perm = torch.argsort(c0 * (g["G"] + 1) + g["item_group"].long(), stable=True)
         for kk in ("item_group", "m0", "m1", "item_out"):
             g[kk] = g[kk][perm].contiguous()
+        if os.environ.get("XCDCHUNK"):
+            # emulate XCD-aware assignment: 8 chunks of equal merged-column work; block b -> chunk b%8
+            ln = (g["m1"] - g["m0"]).long()
+            cs = torch.cumsum(ln, 0)
+            tot = int(cs[-1])
+            bounds = [0] + [int(torch.searchsorted(cs, torch.tensor(tot * k // 8, device=dev))) for k in range(1, 8)] + [ln.numel()]
+            bounds = [(b + 3) // 4 * 4 for b in bounds[:-1]] + [ln.numel()]
+            mx = max(bounds[k + 1] - bounds[k] for k in range(8)); mx = (mx + 3) // 4 * 4
+            nblk = mx // 4
+            idxmap = torch.full((8 * mx,), -1, dtype=torch.long, device=dev)
+            for k in range(8):
+                cnt = bounds[k + 1] - bounds[k]
+                src = torch.arange(cnt, device=dev)
+                blk_in = src // 4; w = src % 4
+                pos = (blk_in * 8 + k) * 4 + w
+                idxmap[pos] = bounds[k] + src
+            valid = idxmap >= 0
+            for kk in ("item_group", "m0", "m1", "item_out"):
+                old = g[kk]
+                new = torch.zeros(8 * mx, dtype=old.dtype, device=dev)
+                new[valid] = old[idxmap[valid]]
+                if kk == "item_out":
+                    new[~valid] = -2
+                g[kk] = new.contiguous()
+            print("xcd chunks (items):", [bounds[k + 1] - bounds[k] for k in range(8)])
         Y = torch.zeros(n, F, device=dev)
         partial = torch.zeros(max(g["nslots"], 1) * R * F, device=dev)
         a = RgArgs()
