@@ -1,0 +1,83 @@
+"""Full-size checks on the benchmark shapes, through properties that need no CPU
+reference of that size:
+
+* the two independent kernels (plain CSR, row-group) agree to fp32 rounding;
+* A_hat . D^1/2 1 = D^1/2 1;  linearity;  the weighted checksum
+  (D^1/2 1)^T A_hat X = (D^1/2 1)^T X  (symmetric A);
+* K hops as one chain equal K single hops;
+* X spanning more than 4 GiB (64-bit addressing path) gives the same rows as a
+  compact copy of the same data.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _graph(shape, dev, seed=1):
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import SHAPES, rmat_undirected_device
+    n, E, F = SHAPES[shape]
+    row, col = rmat_undirected_device(n, E, seed=seed, device=dev)
+    adj = NormAdj.from_coo(row, col, None, n, dev)
+    return adj, n, F
+
+
+def test_reddit_shape_full_size_properties(gpu_device):
+    dev = gpu_device
+    adj, n, F = _graph("reddit", dev)
+    assert adj.nnz > 114_000_000 and adj.unit_weights and adj.symmetric
+    # rowptr / degree invariants of the build at this size
+    counts = (adj.rowptr[1:] - adj.rowptr[:-1])
+    assert int(adj.rowptr[0]) == 0 and int(adj.rowptr[-1]) == adj.nnz and int(counts.min()) >= 1
+    assert torch.equal(adj.deg, counts.float())                      # unit weights: degree = row length
+    assert torch.equal(adj.dinv, 1.0 / counts.float().sqrt())
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    X = torch.randn(n, F, device=dev, generator=g)
+    adj.use_rowgroup = True
+    Y_rg = adj.propagate(X, 1)
+    assert adj._plans, "row-group plan was not used"
+    adj.use_rowgroup = False
+    Y_csr = adj.propagate(X, 1)
+    assert float((Y_rg - Y_csr).norm() / Y_csr.norm()) <= TOL
+    # element-wise against |A_hat| |X|
+    scale = adj.propagate(X.abs(), 1)
+    assert float(((Y_rg - Y_csr).abs() / scale).max()) <= TOL
+    adj.use_rowgroup = True
+    s = adj.deg.sqrt()
+    fixed = adj.propagate(s[:, None].expand(n, 64).contiguous(), 1)
+    assert float(((fixed - s[:, None]).abs() / s[:, None]).max()) <= TOL
+    chk_l = (s.double()[:, None] * Y_rg.double()).sum(0)
+    chk_r = (s.double()[:, None] * X.double()).sum(0)
+    absum = (s.double()[:, None] * X.double().abs()).sum(0)
+    assert float(((chk_l - chk_r).abs() / absum).max()) <= TOL
+    Z = torch.randn(n, F, device=dev, generator=g)
+    lhs = adj.propagate(1.5 * X - 0.25 * Z, 1)
+    rhs = 1.5 * Y_rg - 0.25 * adj.propagate(Z, 1)
+    assert float((lhs - rhs).norm() / rhs.norm()) <= TOL
+    chain = adj.propagate(X, 2)
+    hops = adj.propagate(Y_rg, 1)
+    assert float((chain - hops).norm() / hops.norm()) <= TOL
+
+
+@pytest.mark.parametrize("rowgroup", [True, False])
+def test_x_larger_than_4gib(gpu_device, rowgroup):
+    """Rows of X 16 KiB apart: the matrix spans 4.9 GB, so a row's byte offset does
+    not fit 32 bits and the kernels re-base their buffer descriptor per fetched row."""
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import rmat_undirected_device
+    dev = gpu_device
+    n, F, ld = 300_000, 64, 4096
+    row, col = rmat_undirected_device(n, 6_000_000, seed=2, device=dev)
+    adj = NormAdj.from_coo(row, col, None, n, dev)
+    adj.use_rowgroup = rowgroup
+    big = torch.zeros(n, ld, device=dev)
+    assert big.numel() * 4 > (1 << 32)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    Xc = torch.randn(n, F, device=dev, generator=g)
+    big[:, 100:100 + F] = Xc
+    Y_big = adj.spmm(big[:, 100:100 + F])
+    Y_ref = adj.spmm(Xc)
+    assert float((Y_big - Y_ref).norm() / Y_ref.norm()) <= 1e-6
+    assert torch.equal(Y_big, Y_ref)            # same kernel arithmetic, only the addressing differs
