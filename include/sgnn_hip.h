@@ -41,6 +41,10 @@ extern "C" {
 /* build flags */
 #define SGNN_STRIP_DIAG        1   /* drop (i,i) entries of the input first: model/SGNN.py:497-501 */
 #define SGNN_DROP_ZEROS        2   /* drop entries whose merged value is 0 (scipy's sparse subtraction does) */
+#define SGNN_SYMMETRIZE        4   /* every input (r, c, v) also counts as (c, r, v): adj.T + adj of the loaders,
+                                      data_loader.py:451,476,490,507 (diagonal input entries count twice, as there) */
+#define SGNN_CLAMP_ONE         8   /* merged input weight = min(sum, 1), before any self-loop is added:
+                                      adj.minimum(1), data_loader.py:452,477,491,508 */
 /* self-loop modes */
 #define SGNN_LOOPS_NONE        0
 #define SGNN_LOOPS_ADD         1   /* A + I, diagonal value += 1: utils.py:83-86 */
@@ -63,7 +67,7 @@ int sgnn_tune_set(const char* key, int value);
 const char* sgnn_last_error(void);
 
 /* Bytes of device scratch sgnn_build_norm_csr needs for an n x n matrix given
- * as nnz_in COO entries. */
+ * as nnz_in COO entries (pass 2 * nnz_in when building with SGNN_SYMMETRIZE). */
 size_t sgnn_build_workspace_bytes(int64_t n, int64_t nnz_in);
 
 /*
@@ -78,14 +82,16 @@ size_t sgnn_build_workspace_bytes(int64_t n, int64_t nnz_in);
  *
  *   val        nullable: every entry has weight 1
  *   rowptr     [n+1] int32 out
- *   colidx     [nnz_in + n] int32 out (capacity; *nnz_out entries are valid)
- *   vals       [nnz_in + n] fp32 out
+ *   colidx     [nnz_in + n] int32 out (capacity; *nnz_out entries are valid);
+ *              [2 * nnz_in + n] with SGNN_SYMMETRIZE
+ *   vals       same capacity, fp32 out
  *   deg        [n] fp32 out: row sums in fp32 (64 strided partial sums folded in halves;
  *              exact, hence order-free, for integer-valued weights)
  *   dinv       [n] fp32 out: 1.0f / sqrtf(deg) (two roundings, as utils.py:88-89);
  *              with zero_inf != 0 an infinite result is replaced by 0 (gcn_norm)
  *   nnz_out    device int64 out
- * Duplicates are summed in fp32 in input order; columns are sorted inside a row.
+ * Duplicates are summed in fp32 in input order (with SGNN_SYMMETRIZE: the entries as
+ * given first, then their mirror images in input order); columns are sorted inside a row.
  */
 int sgnn_build_norm_csr(int64_t n, int64_t nnz_in,
                         const int64_t* row, const int64_t* col, const float* val,
@@ -200,6 +206,26 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
  * to pre-scale the row block a rank contributes to the all-gather). */
 int sgnn_row_scale_f32(int64_t n, int64_t F, const float* scale,
                        const float* in, int64_t ldin, float* out, int64_t ldout, void* stream);
+
+/* sampling flags */
+#define SGNN_SAMPLE_SKIP_SELF  1   /* write 0 where idx[i] == idx[j]: sample the matrix without its diagonal */
+
+/*
+ * out[i, j] = A[idx[i], idx[j]] for i, j < b, dense row-major fp32 with row
+ * stride ldo — the b x b block the auto-encoder layer reconstructs per Adam
+ * iteration.  Replaces model/SGNN.py:167-170 (adjacency_npy[idx, :][:, idx],
+ * .todense(), torch.Tensor(...), .to(device)) and, called on the CSR of the
+ * overlook matrix, model/SGNN.py:172-175.
+ *   rowptr/colidx/vals : CSR with column indices ascending within each row
+ *                        (what sgnn_build_norm_csr writes); vals may be null = all 1
+ *   idx                : int64[b] node ids; a repeated id repeats the row/column as
+ *                        fancy indexing does; an id outside [0, n_rows) gives a zero row
+ *   flags              : SGNN_SAMPLE_SKIP_SELF to read a CSR that stores A + I as
+ *                        the diagonal-free A the reference keeps (model/SGNN.py:497-501)
+ */
+int sgnn_sample_block_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                          const float* vals, int64_t b, const int64_t* idx, int flags,
+                          float* out, int64_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

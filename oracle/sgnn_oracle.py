@@ -23,6 +23,8 @@ Reference locations restated here (paths relative to the reference tree):
   * ``reddit_utils.py:49-57``, ``reddit_utils.py:281-288``,
     ``data_loader.py:673-686``  scipy statements of D^-1/2 (A+I) D^-1/2
   * ``model/SGC.py:11,14``, ``model/GCN.py:9-16``  PyG SGConv / GCNConv call sites
+  * ``data_loader.py:451-452``  adj.T + adj, minimum(1) of the loaders
+  * ``model/SGNN.py:167-170``   dense sub-adjacency of a sampled batch
 """
 from __future__ import annotations
 
@@ -282,3 +284,24 @@ def pyg_gcnconv(x, edge_index, weight, bias, edge_weight=None):
     if bias is not None:
         out = out + np.asarray(bias, np.float32)
     return out.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# ingestion and sampling around the path
+# --------------------------------------------------------------------------
+def symmetrize_binarize(row, col, val, n):
+    """The loaders' ``adj = adj.T + adj; adj = adj.minimum(1)``
+    (data_loader.py:451-452, 476-477, 490-491, 507-508) on a COO edge list;
+    returns a scipy CSR in fp32."""
+    val = np.ones(len(row), np.float32) if val is None else np.asarray(val, np.float32)
+    adj = sp.coo_matrix((val, (np.asarray(row), np.asarray(col))), shape=(n, n), dtype=np.float32)
+    adj = adj.T + adj
+    adj = adj.minimum(1)
+    return adj.tocsr()
+
+
+def sample_block(adjacency, idx):
+    """Dense ``adjacency[idx, :][:, idx]`` as fp32 (model/SGNN.py:167-170)."""
+    sub = adjacency.tocsr()[idx, :]
+    sub = sub[:, idx]
+    return np.asarray(sub.todense(), dtype=np.float32)

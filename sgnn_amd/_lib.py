@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libsgnn_hip.so")
 # constants of include/sgnn_hip.h
 STRIP_DIAG = 1
 DROP_ZEROS = 2
+SYMMETRIZE = 4
+CLAMP_ONE = 8
+SAMPLE_SKIP_SELF = 1
 LOOPS_NONE, LOOPS_ADD, LOOPS_REMAINING = 0, 1, 2
 EPI_SCALE_ROW, EPI_SCALE_ROW2 = 0, 1
 
@@ -49,6 +52,8 @@ SIGNATURES = {
                                        ctypes.c_float, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "sgnn_sample_block_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
+                                      c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -61,14 +61,19 @@ BuildWs carve_build(void* base, int64_t m) {
   return w;
 }
 
-__global__ void k_make_keys(int64_t n, int64_t nnz_in, int64_t m, const int64_t* __restrict__ row,
+// Entries [0, nnz_src) are the input triples, [nnz_src, nnz_in) their mirror images
+// (c, r) when the matrix is being symmetrised (nnz_in == 2 * nnz_src then, else
+// nnz_in == nnz_src), [nnz_in, m) the appended self-loop markers.
+__global__ void k_make_keys(int64_t n, int64_t nnz_src, int64_t nnz_in, int64_t m, const int64_t* __restrict__ row,
                             const int64_t* __restrict__ col, int strip, int cbits, uint64_t sentinel,
                             uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, int32_t* __restrict__ flag) {
   int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (i >= m) return;
   uint64_t key;
   if (i < nnz_in) {
-    int64_t r = row[i], c = col[i];
+    const bool mirror = i >= nnz_src;
+    const int64_t e = mirror ? i - nnz_src : i;
+    int64_t r = mirror ? col[e] : row[e], c = mirror ? row[e] : col[e];
     if (r < 0 || r >= n || c < 0 || c >= n) {
       flag[0] = 1;
       key = sentinel;
@@ -87,9 +92,9 @@ __global__ void k_make_keys(int64_t n, int64_t nnz_in, int64_t m, const int64_t*
 
 // One thread per sorted entry; the first entry of a run of equal keys sums the
 // run in sorted (= input, the sort is stable) order.
-__global__ void k_merge_runs(int64_t m, int64_t nnz_in, const uint64_t* __restrict__ keys,
+__global__ void k_merge_runs(int64_t m, int64_t nnz_src, int64_t nnz_in, const uint64_t* __restrict__ keys,
                              const uint32_t* __restrict__ idx, const float* __restrict__ val, uint64_t sentinel,
-                             int cbits, int self_loops, int drop_zeros, float* __restrict__ rsum,
+                             int cbits, int self_loops, int drop_zeros, int clamp_one, float* __restrict__ rsum,
                              uint32_t* __restrict__ keep) {
   int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (i >= m) return;
@@ -99,21 +104,32 @@ __global__ void k_merge_runs(int64_t m, int64_t nnz_in, const uint64_t* __restri
     keep[i] = 0;
     return;
   }
-  float s = 0.0f;
-  bool any = false;
+  float s = 0.0f, s_mirror = 0.0f;
+  bool any = false, open = true;  // open: the input part of the run has not been closed yet
   // REMAINING: a diagonal run keeps the weight of its last input entry (torch_geometric
   // assigns loop weights by index, so later entries overwrite earlier ones), 1 if it has none
   const bool assign = self_loops == SGNN_LOOPS_REMAINING && (key >> cbits) == (key & ((uint64_t(1) << cbits) - 1));
+  // The entries as given and their mirror images are summed separately and the two sums
+  // added once, as (adj.T + adj) adds two matrices whose duplicates are already merged:
+  // the result is bitwise symmetric for any weights.
+  auto close = [&]() {
+    s += s_mirror;
+    if (clamp_one) s = fminf(s, 1.0f);
+    open = false;
+  };
   for (int64_t j = i; j < m && keys[j] == key; ++j) {
     uint32_t id = idx[j];
     if (id < nnz_in) {
-      float v = val ? val[id] : 1.0f;
-      s = assign ? v : s + v;
+      const bool mirror = id >= nnz_src;
+      float v = val ? val[mirror ? id - nnz_src : id] : 1.0f;
+      if (assign) s = v; else if (mirror) s_mirror += v; else s += v;
       any = true;
-    } else if (self_loops == SGNN_LOOPS_ADD || !any) {
-      s += 1.0f;  // the marker is the last entry of its run
+    } else {
+      close();  // the marker is the last entry of its run
+      if (self_loops == SGNN_LOOPS_ADD || !any) s += 1.0f;
     }
   }
+  if (open) close();
   rsum[i] = s;
   keep[i] = (drop_zeros && s == 0.0f) ? 0u : 1u;
 }
@@ -215,9 +231,13 @@ int sgnn_build_norm_csr(int64_t n, int64_t nnz_in, const int64_t* row, const int
                         void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n <= 0 || nnz_in < 0) return fail(SGNN_ERR_INVALID, "n must be positive and nnz_in non-negative");
+  if (flags & ~(SGNN_STRIP_DIAG | SGNN_DROP_ZEROS | SGNN_SYMMETRIZE | SGNN_CLAMP_ONE))
+    return fail(SGNN_ERR_INVALID, "unknown build flag");
+  const int64_t nnz_src = nnz_in;
+  if (flags & SGNN_SYMMETRIZE) nnz_in *= 2;
   if (n >= (int64_t(1) << 31) || nnz_in + n >= (int64_t(1) << 31))
-    return fail(SGNN_ERR_INVALID, "n and nnz_in + n must stay below 2^31");
-  if ((nnz_in > 0 && (!row || !col)) || !rowptr || !colidx || !vals || !deg || !dinv || !nnz_out)
+    return fail(SGNN_ERR_INVALID, "n and the entry count (doubled when symmetrising) + n must stay below 2^31");
+  if ((nnz_src > 0 && (!row || !col)) || !rowptr || !colidx || !vals || !deg || !dinv || !nnz_out)
     return fail(SGNN_ERR_INVALID, "null pointer");
   if (self_loops < SGNN_LOOPS_NONE || self_loops > SGNN_LOOPS_REMAINING)
     return fail(SGNN_ERR_INVALID, "unknown self-loop mode");
@@ -237,14 +257,14 @@ int sgnn_build_norm_csr(int64_t n, int64_t nnz_in, const int64_t* row, const int
     return SGNN_OK;
   }
   const unsigned gm = unsigned((m + T - 1) / T);
-  hipLaunchKernelGGL(k_make_keys, dim3(gm), dim3(T), 0, st, n, nnz_in, m, row, col, (flags & SGNN_STRIP_DIAG) ? 1 : 0,
+  hipLaunchKernelGGL(k_make_keys, dim3(gm), dim3(T), 0, st, n, nnz_src, nnz_in, m, row, col, (flags & SGNN_STRIP_DIAG) ? 1 : 0,
                      cbits, sentinel, w.keys_a, w.idx_a, w.flag);
   HIP_TRY(hipGetLastError());
   size_t pb = w.prim_bytes;
   HIP_TRY(rocprim::radix_sort_pairs(w.prim, pb, w.keys_a, w.keys_b, w.idx_a, w.idx_b, size_t(m), 0u,
                                     unsigned(2 * cbits + 1), st));
-  hipLaunchKernelGGL(k_merge_runs, dim3(gm), dim3(T), 0, st, m, nnz_in, w.keys_b, w.idx_b, val, sentinel, cbits,
-                     self_loops, (flags & SGNN_DROP_ZEROS) ? 1 : 0, w.rsum, w.keep);
+  hipLaunchKernelGGL(k_merge_runs, dim3(gm), dim3(T), 0, st, m, nnz_src, nnz_in, w.keys_b, w.idx_b, val, sentinel, cbits,
+                     self_loops, (flags & SGNN_DROP_ZEROS) ? 1 : 0, (flags & SGNN_CLAMP_ONE) ? 1 : 0, w.rsum, w.keep);
   HIP_TRY(hipGetLastError());
   pb = w.prim_bytes;
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.keep, w.pos, 0u, size_t(m), rocprim::plus<uint32_t>(), st));

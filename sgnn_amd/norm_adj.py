@@ -100,8 +100,13 @@ class NormAdj:
     # ------------------------------------------------------------------ build
     @classmethod
     def from_coo(cls, row, col, val, n, device, strip_diag=False, self_loops=_lib.LOOPS_ADD,
-                 drop_zeros=False, zero_inf=False):
-        """Build from COO triples (duplicates summed; utils.py:54-62 + 82-89)."""
+                 drop_zeros=False, zero_inf=False, symmetrize=False, clamp_one=False):
+        """Build from COO triples (duplicates summed; utils.py:54-62 + 82-89).
+
+        ``symmetrize`` and ``clamp_one`` do the loaders' ``adj = adj.T + adj`` and
+        ``adj = adj.minimum(1)`` (data_loader.py:451-452, 476-477, 490-491, 507-508)
+        on the GPU as part of the same sort-and-merge, so a raw directed edge list
+        goes in and the symmetric 0/1 adjacency is what gets normalised."""
         device = _require_gpu(device)
         lib = _lib.load()
         n = int(n)
@@ -119,16 +124,17 @@ class NormAdj:
                 val = val.to(device=device, dtype=torch.float32).contiguous()
                 if val.numel() != nnz_in:
                     raise ValueError("val must have one entry per (row, col) pair")
-            cap = nnz_in + n
+            cap = nnz_in * (2 if symmetrize else 1) + n
             rowptr = torch.empty(n + 1, dtype=torch.int32, device=device)
             colidx = torch.empty(cap, dtype=torch.int32, device=device)
             vals = torch.empty(cap, dtype=torch.float32, device=device)
             deg = torch.empty(n, dtype=torch.float32, device=device)
             dinv = torch.empty(n, dtype=torch.float32, device=device)
             nnz_out = torch.zeros(1, dtype=torch.int64, device=device)
-            ws_bytes = lib.sgnn_build_workspace_bytes(n, nnz_in)
+            ws_bytes = lib.sgnn_build_workspace_bytes(n, nnz_in * (2 if symmetrize else 1))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-            flags = (_lib.STRIP_DIAG if strip_diag else 0) | (_lib.DROP_ZEROS if drop_zeros else 0)
+            flags = ((_lib.STRIP_DIAG if strip_diag else 0) | (_lib.DROP_ZEROS if drop_zeros else 0)
+                     | (_lib.SYMMETRIZE if symmetrize else 0) | (_lib.CLAMP_ONE if clamp_one else 0))
             _lib.check(lib.sgnn_build_norm_csr(
                 n, nnz_in, _lib.ptr(row), _lib.ptr(col), _lib.ptr(val), flags, int(self_loops),
                 1 if zero_inf else 0, _lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(vals), _lib.ptr(deg),
@@ -312,6 +318,27 @@ class NormAdj:
                           _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2)
                 src = dst
         return Y
+
+    # --------------------------------------------------------------- sampling
+    def sample_block(self, idx, skip_self=True, out=None):
+        """Dense ``A[idx, :][:, idx]`` as fp32 on the GPU (model/SGNN.py:167-170).
+
+        The stored matrix carries the self-loops the build added; ``skip_self``
+        writes 0 where ``idx[i] == idx[j]``, which is the block of the diagonal-free
+        adjacency the reference samples from (model/SGNN.py:497-501)."""
+        idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
+        if idx.dim() != 1:
+            raise ValueError("idx must be 1-D")
+        b = int(idx.numel())
+        if out is None:
+            out = torch.empty((b, b), dtype=torch.float32, device=self.device)
+        elif out.shape != (b, b) or out.dtype != torch.float32 or out.device != self.device or out.stride(1) != 1:
+            raise ValueError("out must be a [b, b] fp32 tensor with unit column stride on the adjacency's device")
+        _lib.check(_lib.load().sgnn_sample_block_f32(
+            self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), _lib.ptr(self.vals), b, _lib.ptr(idx),
+            _lib.SAMPLE_SKIP_SELF if skip_self else 0, _lib.ptr(out), out.stride(0) if b > 1 else b,
+            _lib.current_stream(self.device)))
+        return out
 
     # -------------------------------------------------------------- transpose
     def transpose(self):

@@ -1,10 +1,12 @@
 """Decoupled stacked-GNN training on top of the propagation boundary.
 
-This is the caller side of the hot path: the supervised stacked model of the
-reference (``SupervisedStackedGNN`` with embedding-GCN layers, the only layer
-type its classification runner builds — GNN_tasks.py:76-87) restated in plain
-PyTorch so that the end-to-end accuracy of the reference can be reproduced above
-``sgnn_amd.utils``.  The numerics that matter for parity follow the reference:
+This is the caller side of the hot path: the stacked models of the reference —
+``SupervisedStackedGNN`` with embedding-GCN layers (the only layer type its
+classification runner builds, GNN_tasks.py:76-87) and ``StackedGNN`` with graph
+auto-encoder layers (the clustering runner, GNN_tasks.py:325-356) — restated in
+plain PyTorch so that the end-to-end accuracy / NMI of the reference can be
+reproduced above ``sgnn_amd.utils``.  The numerics that matter for parity follow
+the reference:
 
 * a layer is ``act(inner_act(X' U) W)`` with ``X' = A_hat^order X``
   (model/SGNN.py:73-78, 404-405), ``U`` starting at the identity;
@@ -16,7 +18,14 @@ PyTorch so that the end-to-end accuracy of the reference can be reproduced above
   with one (model/SGNN.py:80-86, 388-399), a second target term on a batch drawn
   from all nodes (model/SGNN.py:425-429), ridge penalty ``lam * (|W|^2+|b|^2+|U|^2)``
   (model/SGNN.py:88-92), a fresh Adam per ``run`` (model/SGNN.py:417), batches drawn
-  as the head of a random permutation (model/SGNN.py:115-117).
+  as the head of a random permutation (model/SGNN.py:115-117);
+* auto-encoder layers reconstruct the dense sub-adjacency of the batch through
+  ``sigmoid(clamp(Z Z^T, +-40))`` under the positive-reweighted cross-entropy with a
+  random symmetric ignore mask merged with the overlook matrix
+  (model/SGNN.py:138-164, 209-226, 682-702) and a lasso penalty
+  (model/SGNN.py:93-96, 543); the batch's sub-adjacency is read from the CSR on
+  the GPU (``NormAdj.sample_block``) instead of scipy fancy indexing plus a
+  host-to-device copy per iteration (model/SGNN.py:167-175).
 
 What differs, on purpose (these are the residency items the reference leaves on
 the table): features, targets and embeddings stay on the GPU instead of bouncing
@@ -65,6 +74,7 @@ def get_activation(spec):
 class LayerParam:
     """Per-layer hyper-parameters (model/SGNN.py:729-758)."""
     GAE, GCN, EGCN = 0, 1, 2
+    MASK_RATE = "mask_rate"
 
     def __init__(self, neurons, inner_act=None, act=None, gnn_type=EGCN, **kwargs):
         self.neurons = neurons
@@ -82,10 +92,10 @@ def _glorot(rows, cols, device):
     return torch.nn.Parameter((torch.rand(rows, cols, device=device) * 2 - 1) * bound)
 
 
-class EmbeddingLayer(torch.nn.Module):
-    """One decoupled layer with a label head (SingleLayerEmbeddingGCN, model/SGNN.py:357-467)."""
+class _Layer(torch.nn.Module):
+    """What every decoupled layer shares (SingleLayerGNN, model/SGNN.py:18-117)."""
 
-    def __init__(self, adjacency, labels, train_mask, input_dim, embedding_dim, n_class, p, device):
+    def __init__(self, adjacency, input_dim, embedding_dim, p, device):
         super().__init__()
         self.adjacency, self.device = adjacency, device
         self.order = p.get("order", 1)
@@ -97,8 +107,6 @@ class EmbeddingLayer(torch.nn.Module):
         self.W = _glorot(input_dim, embedding_dim, device)
         self.b = _glorot(1, embedding_dim, device)
         self.U = torch.nn.Parameter(torch.eye(input_dim, device=device), requires_grad=False)
-        self.Wt = _glorot(embedding_dim, n_class, device)
-        self.labels, self.train_mask = labels, train_mask
         self.expected_X = None
         self._cache_in, self._cache_version, self._cache_val = None, -1, None
 
@@ -121,11 +129,29 @@ class EmbeddingLayer(torch.nn.Module):
             self._cache_in, self._cache_version = X, X._version
         return self._cache_val
 
-    def _penalty(self):
+    def _ridge(self):
         return self.W.pow(2).sum() + self.b.pow(2).sum() + self.U.pow(2).sum()
+
+    def _lasso(self):
+        return self.W.abs().sum() + self.b.abs().sum() + self.U.abs().sum()
 
     def _batch(self, rows):
         return torch.randperm(rows, device=self.device)[:self.batch_size]
+
+    def _finish(self, X, PX):
+        with torch.no_grad():
+            embedding = self(PX)
+            self.expected_X = X.matmul(self.U)
+        return embedding
+
+
+class EmbeddingLayer(_Layer):
+    """One decoupled layer with a label head (SingleLayerEmbeddingGCN, model/SGNN.py:357-467)."""
+
+    def __init__(self, adjacency, labels, train_mask, input_dim, embedding_dim, n_class, p, device):
+        super().__init__(adjacency, input_dim, embedding_dim, p, device)
+        self.Wt = _glorot(embedding_dim, n_class, device)
+        self.labels, self.train_mask = labels, train_mask
 
     def run(self, X, embedding_target=None, eta=1, train=True):
         PX = self.propagated(X)
@@ -142,50 +168,88 @@ class EmbeddingLayer(torch.nn.Module):
                     loss = Fn.cross_entropy(emb.matmul(self.Wt), tY[idx])
                 else:
                     loss = eta * (emb - tT[idx]).pow(2).sum() / emb.shape[0]
-                loss = loss + self.lam * self._penalty()
+                loss = loss + self.lam * self._ridge()
                 if embedding_target is not None:
                     jdx = self._batch(PX.shape[0])
                     e2 = self(PX[jdx])
                     loss = loss + eta * (e2 - embedding_target[jdx]).pow(2).sum() / e2.shape[0]
                 loss.backward()
                 opt.step()
-        with torch.no_grad():
-            embedding = self(PX)
-            self.expected_X = X.matmul(self.U)
-        return embedding
+        return self._finish(X, PX)
 
     @torch.no_grad()
     def predict(self, embedding):
         return embedding.matmul(self.Wt).argmax(dim=1)
 
 
-class SupervisedStackedGNN:
-    """Stack of decoupled layers with forward / backward sweeps
-    (model/SGNN.py:470-600, 628-679).  ``run()`` returns the predicted labels of
-    all nodes as a numpy array."""
+class GAELayer(_Layer):
+    """One decoupled graph auto-encoder layer (SingleLayerGAE, model/SGNN.py:120-251)."""
 
-    def __init__(self, content, adjacency, layers, training_mask, val_mask=None, labels=None,
-                 overlooked_rates=None, eta=1, BP_count=0, device=None, metric_func=None, logger=None, rank=None):
-        if labels is None:
-            raise ValueError("labels are required")
+    def __init__(self, adjacency, input_dim, embedding_dim, p, device, overlook=None):
+        super().__init__(adjacency, input_dim, embedding_dim, p, device)
+        self.mask_rate = p.get(LayerParam.MASK_RATE, 0.0)
+        # entries to leave out of the reconstruction loss besides the diagonal: a
+        # handle on the symmetric 0/1 overlook matrix, or None for "diagonal only"
+        # (overlooked_rate 0: utils.py:47-51)
+        self.overlook = overlook
+
+    def decode(self, embedding):
+        return torch.sigmoid(embedding.matmul(embedding.t()).clamp(-40.0, 40.0))     # model/SGNN.py:138-142
+
+    def _ignore_mask(self, idx):
+        b = idx.numel()
+        mask = (torch.rand(b, b, device=self.device) <= self.mask_rate).float()       # model/SGNN.py:209-226
+        mask = mask.maximum(mask.t())
+        mask = mask - mask.diag().diag()
+        if self.overlook is None:
+            look = (idx[:, None] == idx[None, :]).float()       # self-loop part of the overlook matrix
+        else:
+            look = self.overlook.sample_block(idx, skip_self=False)
+        return mask.maximum(look)
+
+    @staticmethod
+    def reconstruction_loss(recons, target, retain):
+        """Positive-reweighted cross-entropy over retained entries (model/SGNN.py:682-702),
+        without the host round trip of ``if num_positive > 0``."""
+        num_positive = (target * retain).sum()
+        ratio = retain.sum() / num_positive.clamp_min(1.0) - 1
+        pos = (-ratio * target * torch.log(recons.clamp_min(1e-6)) * retain).mean()
+        pos = torch.where(num_positive > 0, pos, torch.zeros_like(pos))
+        neg = (-(1 - target) * torch.log((1 - recons).clamp_min(1e-6)) * retain).mean()
+        return pos + neg
+
+    def run(self, X, embedding_target=None, eta=1, train=True):
+        PX = self.propagated(X)
+        if train:
+            opt = torch.optim.Adam([q for q in self.parameters()], lr=self.lr)
+            for _ in range(self.max_iter):
+                opt.zero_grad()
+                idx = self._batch(PX.shape[0])
+                target = self.adjacency.sample_block(idx, skip_self=True)              # model/SGNN.py:167-170
+                emb = self(PX[idx])
+                loss = self.reconstruction_loss(self.decode(emb), target, 1 - self._ignore_mask(idx))
+                loss = loss + self.lam * self._lasso()
+                if embedding_target is not None:
+                    loss = loss + eta * (emb - embedding_target[idx]).pow(2).sum() / emb.shape[0]
+                loss.backward()
+                opt.step()
+        return self._finish(X, PX)
+
+
+class _Stack:
+    """Forward / backward sweeps over decoupled layers (StackedGNN, model/SGNN.py:470-600)."""
+
+    def __init__(self, content, adjacency, eta, BP_count, device, labels, metric_func, logger):
         self.device = torch.device(device if device is not None else "cuda:0")
         A = adjacency.tocsr()
         A = A - _diag_of(A)                                       # model/SGNN.py:497-501
+        self.adjacency = A
         self.adjacency_tensor = prop.csr_to_sparse_Tensor(A, self.device)
         self.content = torch.as_tensor(np.asarray(content), dtype=torch.float32).to(self.device)
-        self.labels = torch.as_tensor(np.asarray(labels)).long().to(self.device)
-        self.training_mask = torch.as_tensor(np.asarray(training_mask)).to(self.device)
         self.eta, self.BP_count = eta, int(BP_count)
+        self.labels_host = None if labels is None else np.asarray(labels)
         self.metric_func, self.logger = metric_func, logger
-        n_class = int(np.unique(np.asarray(labels)).shape[0])
         self.gnns = []
-        dim = self.content.shape[1]
-        for p in layers:
-            if p.gnn_type != LayerParam.EGCN:
-                raise NotImplementedError("only embedding-GCN layers (the classification runner's type) are built")
-            self.gnns.append(EmbeddingLayer(self.adjacency_tensor, self.labels, self.training_mask, dim,
-                                            p.neurons, n_class, p, self.device))
-            dim = p.neurons
 
     def _forward_sweep(self, with_targets):
         inputs, x = [], self.content
@@ -204,12 +268,121 @@ class SupervisedStackedGNN:
             g.run(inputs[i], embedding_target=target, eta=self.eta)
             target = g.expected_X
 
-    def run(self):
+    def _report(self, embedding):
+        if self.labels_host is not None and self.metric_func is not None:          # model/SGNN.py:550-551
+            self.metric_func(embedding.detach().cpu().numpy(), self.labels_host)
+
+    def _train(self):
         inputs, embedding = self._forward_sweep(False)
+        self._report(embedding)
         for _ in range(self.BP_count):
             self._backward_sweep(inputs)
             inputs, embedding = self._forward_sweep(True)
+            self._report(embedding)
+        return embedding
+
+
+class StackedGNN(_Stack):
+    """Unsupervised stack of auto-encoder layers (model/SGNN.py:470-564).  ``run()``
+    returns the final embedding, on the device."""
+
+    def __init__(self, content, adjacency, layers, overlooked_rates=None, eta=1, BP_count=0, device=None,
+                 labels=None, metric_func=None, logger=None, rank=None):
+        super().__init__(content, adjacency, eta, BP_count, device, labels, metric_func, logger)
+        rates = [0.0] * len(layers) if overlooked_rates is None else list(overlooked_rates)
+        dim = self.content.shape[1]
+        for p, rate in zip(layers, rates):
+            if p.gnn_type != LayerParam.GAE:
+                raise NotImplementedError("the unsupervised stack builds auto-encoder layers only "
+                                          "(model/SGNN.py:530-534 leaves the others unimplemented)")
+            self.gnns.append(GAELayer(self.adjacency_tensor, dim, p.neurons, p, self.device,
+                                      overlook=self._overlook(rate)))
+            dim = p.neurons
+
+    def _overlook(self, rate):
+        """Symmetric random subset of the edges plus the diagonal (utils.py:14-51),
+        resident on the GPU; ``None`` when only the diagonal is overlooked."""
+        rate = min(max(rate, 0), 1)
+        coo = self.adjacency.tocoo()
+        take = int(rate * coo.nnz)
+        if take == 0:
+            return None
+        from .norm_adj import NormAdj
+        pick = torch.randperm(coo.nnz)[:take].numpy()
+        # mirror images and the diagonal are added by the build; weights clamp to 1
+        return NormAdj.from_coo(coo.row[pick], coo.col[pick], None, coo.shape[0], self.device,
+                                symmetrize=True, clamp_one=True, strip_diag=True)
+
+    def run(self):
+        return self._train()
+
+
+class SupervisedStackedGNN(_Stack):
+    """Stack of decoupled layers with a label head (model/SGNN.py:628-679).  ``run()``
+    returns the predicted labels of all nodes as a numpy array."""
+
+    def __init__(self, content, adjacency, layers, training_mask, val_mask=None, labels=None,
+                 overlooked_rates=None, eta=1, BP_count=0, device=None, metric_func=None, logger=None, rank=None):
+        if labels is None:
+            raise ValueError("labels are required")
+        super().__init__(content, adjacency, eta, BP_count, device, None, metric_func, logger)
+        self.labels = torch.as_tensor(np.asarray(labels)).long().to(self.device)
+        self.training_mask = torch.as_tensor(np.asarray(training_mask)).to(self.device)
+        n_class = int(np.unique(np.asarray(labels)).shape[0])
+        dim = self.content.shape[1]
+        for p in layers:
+            if p.gnn_type != LayerParam.EGCN:
+                raise NotImplementedError("only embedding-GCN layers (the classification runner's type) are built")
+            self.gnns.append(EmbeddingLayer(self.adjacency_tensor, self.labels, self.training_mask, dim,
+                                            p.neurons, n_class, p, self.device))
+            dim = p.neurons
+
+    def run(self):
+        embedding = self._train()
         return self.gnns[-1].predict(embedding).cpu().numpy()
+
+
+# ----------------------------------------------------------------- evaluation
+def clustering_accuracy(truth, prediction):
+    """Best one-to-one relabelling accuracy (metric.py:103-139; the assignment
+    problem is solved with scipy instead of the munkres package)."""
+    from scipy.optimize import linear_sum_assignment
+    truth, prediction = np.asarray(truth).ravel(), np.asarray(prediction).ravel()
+    t_ids, t = np.unique(truth, return_inverse=True)
+    p_ids, q = np.unique(prediction, return_inverse=True)
+    if t_ids.size != p_ids.size:
+        return 0.0                                                # metric.py:109-111
+    hits = np.zeros((t_ids.size, p_ids.size), dtype=np.int64)
+    np.add.at(hits, (t, q), 1)
+    rows, cols = linear_sum_assignment(-hits)
+    return float(hits[rows, cols].sum()) / truth.size
+
+
+def clustering_metrics(truth, prediction):
+    from sklearn.metrics import normalized_mutual_info_score
+    return clustering_accuracy(truth, prediction), float(normalized_mutual_info_score(truth, prediction))
+
+
+def k_means(embedding, n_clusters, labels, replicates=1, seed=None):
+    """Mean ACC / NMI of ``replicates`` k-means runs (utils.py:99-107)."""
+    from sklearn.cluster import KMeans
+    acc = nmi = 0.0
+    for i in range(replicates):
+        km = KMeans(n_clusters=n_clusters, random_state=None if seed is None else seed + i).fit(embedding)
+        a, m = clustering_metrics(labels, km.predict(embedding))
+        acc, nmi = acc + a, nmi + m
+    return acc / replicates, nmi / replicates
+
+
+def relaxed_k_means(X, n_clusters, labels, seed=None):
+    """k-means on the row-normalised top singular vectors (utils.py:117-128)."""
+    from sklearn.cluster import KMeans
+    U, _, _ = torch.linalg.svd(X, full_matrices=False)
+    ind = U[:, :n_clusters]
+    ind = ind / ind.norm(dim=1, keepdim=True).clamp_min(1e-7)
+    ind = ind.cpu().numpy()
+    km = KMeans(n_clusters=n_clusters, random_state=seed).fit(ind)
+    return clustering_metrics(labels, km.predict(ind))
 
 
 def _diag_of(A):

@@ -55,6 +55,15 @@ def test_argument_errors_are_reported_not_crashes():
     assert rc == -1
     with pytest.raises(_lib.SgnnHipError):
         _lib.check(rc)
+    rc = lib.sgnn_build_norm_csr(4, 2, None, None, None, 64, 1, 0, None, None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"flag" in lib.sgnn_last_error()
+    rc = lib.sgnn_sample_block_f32(4, 4, None, None, None, 3, None, 0, None, 3, None)
+    assert rc == -1 and b"null" in lib.sgnn_last_error()
+    rc = lib.sgnn_sample_block_f32(4, 4, None, None, None, 3, None, 2, None, 3, None)
+    assert rc == -1 and b"flag" in lib.sgnn_last_error()
+    rc = lib.sgnn_sample_block_f32(4, 4, None, None, None, 3, None, 0, None, 2, None)
+    assert rc == -1 and b"ldo" in lib.sgnn_last_error()
+    assert lib.sgnn_sample_block_f32(4, 4, None, None, None, 0, None, 0, None, 0, None) == 0
 
 
 def test_no_cpu_fallback():
