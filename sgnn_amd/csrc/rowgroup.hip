@@ -281,17 +281,13 @@ struct RgArgs {
   int32_t items, n_long, F, row_bytes, y_vec, epilogue, seg;
 };
 
-template <int R, int V, int C, int UU, bool HASD, bool BIGX>
-__device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, int32_t cols, uint32_t masks, float ws,
-                                        int k, const int (&boff)[C], float (&acc)[R][C][V]) {
-  float xv[UU][C][V];
-  uint32_t mk[UU];
-  float w[UU];
+// Issue the fetches of UU consecutive merged columns (lanes k .. k+UU-1 of `cols`).
+template <int V, int C, int UU, bool BIGX>
+__device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t cols, int k, const int (&boff)[C],
+                                        float (&xv)[UU][C][V]) {
 #pragma unroll
   for (int u = 0; u < UU; ++u) {
     const int32_t col = __builtin_amdgcn_readlane(cols, k + u);
-    mk[u] = uint32_t(__builtin_amdgcn_readlane(int(masks), k + u));
-    if constexpr (HASD) w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), k + u));
     if constexpr (BIGX) {   // X spans 4 GiB or more: re-base the descriptor on the fetched row
       const i32x4 rr = make_rsrc(a.X + int64_t(col) * a.ldx, uint32_t(a.F) * 4u);
 #pragma unroll
@@ -302,19 +298,29 @@ __device__ __forceinline__ void rg_step(const RgArgs& a, i32x4 rsrc, int32_t col
       for (int c = 0; c < C; ++c) buffer_load_vec<V>(rsrc, boff[c], soff, xv[u][c]);
     }
   }
+}
+
+// Add the fetched rows into the accumulators of the rows whose mask bit is set.
+template <int R, int V, int C, int UU, bool HASD>
+__device__ __forceinline__ void rg_accum(uint32_t masks, float ws, int k, const float (&xv)[UU][C][V],
+                                         float (&acc)[R][C][V]) {
 #pragma unroll
-  for (int u = 0; u < UU; ++u)
+  for (int u = 0; u < UU; ++u) {
+    const uint32_t mk = uint32_t(__builtin_amdgcn_readlane(int(masks), k + u));
+    float w = 1.0f;
+    if constexpr (HASD) w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), k + u));
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (mk[u] & (1u << r)) {   // wave-uniform: a scalar bit test and branch
+      if (mk & (1u << r)) {   // wave-uniform: a scalar bit test and branch
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            if constexpr (HASD) acc[r][c][v] = fmaf(w[u], xv[u][c][v], acc[r][c][v]);
+            if constexpr (HASD) acc[r][c][v] = fmaf(w, xv[u][c][v], acc[r][c][v]);
             else acc[r][c][v] += xv[u][c][v];
           }
       }
+  }
 }
 
 // Row epilogue.  `s` is the pattern sum (every stored entry counted once).  For an
@@ -374,6 +380,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
     nmask = a.gmask[m0 + lane];
     if constexpr (HASD) nws = a.dinv_col[ncols];
   }
+  // Two fetch buffers: while the rows of one step are added, the fetches of the
+  // following step are already in flight (also across the 64-column batches).
+  // Invariant at the top of a batch: xa holds the batch's step 0 iff the batch has
+  // at least U columns.  Every batch but an item's last is full and 64 / U is even,
+  // so an odd number of full steps can only occur in the last batch.
+  float xa[U][C][V], xb[U][C][V];
+  if (min(kWave, m1 - m0) >= U) rg_load<V, C, U, BIGX>(a, rsrc, ncols, 0, boff, xa);
   for (int m = m0; m < m1; m += kWave) {
     const int32_t cols = ncols;
     const uint32_t masks = nmask;
@@ -384,17 +397,27 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
     if (more) {
       ncols = mine ? a.gcol[m + kWave + lane] : 0;
       nmask = mine ? a.gmask[m + kWave + lane] : 0u;
+      if constexpr (HASD) nws = mine ? a.dinv_col[ncols] : 0.0f;
     }
+    const int nfull = cnt / U * U;
+    const bool next_full_step = more && (m1 - (m + kWave)) >= U;
     int k = 0;
-    if (cnt >= U) {
-      rg_step<R, V, C, U, HASD, BIGX>(a, rsrc, cols, masks, ws, 0, boff, acc);
-      k = U;
+    for (; k + 2 * U <= nfull; k += 2 * U) {
+      rg_load<V, C, U, BIGX>(a, rsrc, cols, k + U, boff, xb);
+      rg_accum<R, V, C, U, HASD>(masks, ws, k, xa, acc);
+      if (k + 2 * U < nfull) rg_load<V, C, U, BIGX>(a, rsrc, cols, k + 2 * U, boff, xa);
+      else if (next_full_step) rg_load<V, C, U, BIGX>(a, rsrc, ncols, 0, boff, xa);
+      rg_accum<R, V, C, U, HASD>(masks, ws, k + U, xb, acc);
     }
-    if constexpr (HASD) {
-      if (more) nws = mine ? a.dinv_col[ncols] : 0.0f;   // the ids of the next batch have landed by now
+    if (k < nfull) {   // odd count of full steps: last batch only, xa holds the step
+      rg_accum<R, V, C, U, HASD>(masks, ws, k, xa, acc);
+      k += U;
     }
-    for (; k + U <= cnt; k += U) rg_step<R, V, C, U, HASD, BIGX>(a, rsrc, cols, masks, ws, k, boff, acc);
-    for (; k < cnt; ++k) rg_step<R, V, C, 1, HASD, BIGX>(a, rsrc, cols, masks, ws, k, boff, acc);
+    for (; k < cnt; ++k) {
+      float x1[1][C][V];
+      rg_load<V, C, 1, BIGX>(a, rsrc, cols, k, boff, x1);
+      rg_accum<R, V, C, 1, HASD>(masks, ws, k, x1, acc);
+    }
   }
 
   const int out = a.item_out[item];
