@@ -24,6 +24,7 @@ namespace {
 using namespace sgnn;
 
 constexpr int kWavesPerBlock = 4;
+constexpr int kXcds = 8;   // workgroup b of a 1-D grid runs on XCD b % 8
 
 // Merged columns one wavefront walks; longer lists are cut into segments of this
 // length.  A wavefront works through its list serially, so small graphs get short
@@ -50,8 +51,8 @@ struct Plan {
   int32_t* item_out;    // -1: the item is its group's only one and writes Y; else partial slot
   int32_t* long_group;  // [cap_long] groups with several items
   int32_t* long_slot;   // [cap_long] first partial slot of the group
-  int64_t* counts;      // [8] merged, items, partial slots, long groups, segment length
-  int64_t G, cap_items, cap_long;
+  int64_t* counts;      // [8] merged, launch slots, partial slots, long groups, segment length, items
+  int64_t G, cap_items, cap_long, cap_slots;
   size_t total;
 };
 
@@ -66,10 +67,13 @@ Plan carve_plan(void* base, int64_t n_rows, int64_t nnz, int R) {
   p.gptr = c.take<int32_t>(size_t(p.G) + 1);
   p.gcol = c.take<int32_t>(size_t(nnz));
   p.gmask = c.take<uint32_t>(size_t(nnz));
-  p.item_group = c.take<int32_t>(size_t(p.cap_items));
-  p.item_m0 = c.take<int32_t>(size_t(p.cap_items));
-  p.item_m1 = c.take<int32_t>(size_t(p.cap_items));
-  p.item_out = c.take<int32_t>(size_t(p.cap_items));
+  // launch slots: the items are dealt out to the 8 XCDs in work-balanced runs, padded
+  // to the longest run (see k_item_deal), so up to 8x the item count
+  p.cap_slots = kXcds * (p.cap_items + kWavesPerBlock);
+  p.item_group = c.take<int32_t>(size_t(p.cap_slots));
+  p.item_m0 = c.take<int32_t>(size_t(p.cap_slots));
+  p.item_m1 = c.take<int32_t>(size_t(p.cap_slots));
+  p.item_out = c.take<int32_t>(size_t(p.cap_slots));
   p.long_group = c.take<int32_t>(size_t(p.cap_long));
   p.long_slot = c.take<int32_t>(size_t(p.cap_long));
   p.total = c.off;
@@ -85,6 +89,8 @@ struct BuildWs {
   uint32_t *nseg, *first, *lseg, *slot0, *lflag, *lidx;
   uint64_t *ikey_a, *ikey_b;   // item ordering
   int32_t* itmp;               // [4 * cap_items]
+  uint32_t *ilen, *icum;       // [cap_items] merged columns per item in launch order, running sum
+  int32_t* xbound;             // [kXcds + 1] first item of every XCD's run, [kXcds + 1] = dealing on
   void* prim;
   size_t prim_bytes;
   size_t total;
@@ -114,6 +120,9 @@ BuildWs carve_build(void* base, int64_t n_rows, int64_t nnz, int R) {
   w.ikey_a = c.take<uint64_t>(cap_items);
   w.ikey_b = c.take<uint64_t>(cap_items);
   w.itmp = c.take<int32_t>(4 * cap_items);
+  w.ilen = c.take<uint32_t>(cap_items);
+  w.icum = c.take<uint32_t>(cap_items);
+  w.xbound = c.take<int32_t>(kXcds + 2);
   size_t s1 = 0, s2 = 0, s3 = 0;
   uint64_t* k64 = nullptr;
   uint32_t* k32 = nullptr;
@@ -228,7 +237,7 @@ __global__ void k_items(int64_t G, int kSegCols, const int32_t* __restrict__ gpt
     long_slot[lidx[g]] = int32_t(slot0[g]);
   }
   if (g == G - 1) {
-    counts[1] = int64_t(first[g]) + ns;
+    counts[5] = int64_t(first[g]) + ns;
     counts[2] = int64_t(slot0[g]) + (ns > 1 ? ns : 0);
     counts[3] = int64_t(lidx[g]) + (ns > 1 ? 1 : 0);
     counts[4] = kSegCols;
@@ -244,7 +253,7 @@ __global__ void k_item_keys(int64_t cap_items, const int64_t* __restrict__ count
                             const int32_t* __restrict__ gcol, uint64_t* __restrict__ keys) {
   int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (it >= cap_items) return;
-  keys[it] = it < counts[1] ? ((uint64_t(gcol[item_m0[it]] / kOrderCols) << 32) | uint64_t(it)) : ~uint64_t(0);
+  keys[it] = it < counts[5] ? ((uint64_t(gcol[item_m0[it]] / kOrderCols) << 32) | uint64_t(it)) : ~uint64_t(0);
 }
 
 __global__ void k_item_copy(int64_t cap_items, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
@@ -257,16 +266,83 @@ __global__ void k_item_copy(int64_t cap_items, const int32_t* __restrict__ a, co
   tmp[3 * cap_items + it] = d[it];
 }
 
-__global__ void k_item_permute(int64_t cap_items, const int64_t* __restrict__ counts, const uint64_t* __restrict__ keys,
-                               const int32_t* __restrict__ tmp, int32_t* __restrict__ a, int32_t* __restrict__ b,
-                               int32_t* __restrict__ c, int32_t* __restrict__ d) {
+__global__ void k_item_len(int64_t cap_items, const int64_t* __restrict__ counts, const uint64_t* __restrict__ keys,
+                           const int32_t* __restrict__ tmp, uint32_t* __restrict__ len) {
   int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-  if (it >= counts[1]) return;
+  if (it >= cap_items) return;
+  uint32_t l = 0;
+  if (it < counts[5]) {
+    const int64_t src = int64_t(keys[it] & 0xffffffffu);
+    l = uint32_t(tmp[2 * cap_items + src] - tmp[cap_items + src]);
+  }
+  len[it] = l;
+}
+
+// Cut the ordered item list into kXcds consecutive runs of equal merged-column work
+// (run starts rounded up to whole workgroups).  One thread per boundary.
+// Dealing pays where the gather bounds the kernel and rows share columns (measured on
+// the Reddit shape, R = 16: 12.5 -> 11.3 ms); on sparse graphs whose merged lists are
+// barely shorter than the rows (merged > 3/4 of the entries) and for the narrow-row
+// R = 8 plans it only adds padding slots, so those keep one run: bound[1..] = items.
+__global__ void k_xcd_bounds(const uint32_t* __restrict__ cum, int64_t* __restrict__ counts,
+                             int32_t* __restrict__ bound, int R, int64_t nnz) {
+  __shared__ int32_t b[kXcds + 1];
+  const int k = threadIdx.x;
+  const int64_t items = counts[5];
+  const bool deal = R == 16 && counts[0] * 4 < nnz * 3;
+  if (k <= kXcds) {
+    int64_t pos = items;
+    if (k == 0) pos = 0;
+    else if (deal && k < kXcds && items > 0) {
+      const uint64_t want = uint64_t(cum[items - 1]) * uint64_t(k) / kXcds;
+      int64_t lo = 0, hi = items;   // first item whose running sum reaches `want`
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (uint64_t(cum[mid]) < want) lo = mid + 1; else hi = mid;
+      }
+      pos = min(items, (lo + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock);
+    }
+    b[k] = int32_t(pos);
+    bound[k] = int32_t(pos);
+  }
+  __syncthreads();
+  if (k == 0) {
+    int32_t mx = 0;
+    for (int q = 0; q < kXcds; ++q) mx = max(mx, b[q + 1] - b[q]);
+    mx = (mx + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
+    counts[1] = deal ? int64_t(mx) * kXcds : int64_t(mx);   // launch slots
+    bound[kXcds + 1] = deal ? 1 : 0;
+  }
+}
+
+__global__ void k_item_fill(int64_t cap_slots, int32_t* __restrict__ a, int32_t* __restrict__ b,
+                            int32_t* __restrict__ c, int32_t* __restrict__ d) {
+  int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (it >= cap_slots) return;
+  a[it] = 0;
+  b[it] = 0;
+  c[it] = 0;
+  d[it] = -2;   // padding slot: nothing to do
+}
+
+// Deal the ordered items out so that workgroup b (4 consecutive launch slots) takes
+// its items from run b % kXcds: each XCD then works through one contiguous stretch of
+// the column-ordered list, and its L2 is not shared with seven other stretches.
+__global__ void k_item_deal(int64_t cap_items, const int64_t* __restrict__ counts, const uint64_t* __restrict__ keys,
+                            const int32_t* __restrict__ tmp, const int32_t* __restrict__ bound,
+                            int32_t* __restrict__ a, int32_t* __restrict__ b, int32_t* __restrict__ c,
+                            int32_t* __restrict__ d) {
+  int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (it >= counts[5]) return;
+  int k = 0;
+  while (k + 1 < kXcds && it >= bound[k + 1]) ++k;
+  const int64_t j = it - bound[k];
+  const int64_t pos = bound[kXcds + 1] ? ((j / kWavesPerBlock) * kXcds + k) * kWavesPerBlock + j % kWavesPerBlock : it;
   const int64_t src = int64_t(keys[it] & 0xffffffffu);
-  a[it] = tmp[src];
-  b[it] = tmp[cap_items + src];
-  c[it] = tmp[2 * cap_items + src];
-  d[it] = tmp[3 * cap_items + src];
+  a[pos] = tmp[src];
+  b[pos] = tmp[cap_items + src];
+  c[pos] = tmp[2 * cap_items + src];
+  d[pos] = tmp[3 * cap_items + src];
 }
 
 // ---- the kernel ------------------------------------------------------------------
@@ -352,12 +428,12 @@ __device__ __forceinline__ float rg_epilogue(const RgArgs& a, float s, int row, 
 template <int R, int V, int C, int U, bool HASD, bool BIGX>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
-  // Items are taken in launch order.  (Giving each XCD one contiguous eighth of the
-  // column-ordered list was measured: equal item counts per XCD leave some XCDs idle,
-  // 13.3 vs 12.9 ms on the Reddit shape; work-balanced eighths gain ~6 % and are not
-  // implemented yet.)
+  // Launch slots are laid out so that the workgroups of one XCD walk one contiguous,
+  // work-balanced stretch of the column-ordered item list (k_item_deal).
   const int item = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * kWavesPerBlock + int(threadIdx.x) / kWave);
   if (item >= a.items) return;
+  const int out = a.item_out[item];
+  if (out < -1) return;   // padding slot
   const int g = a.item_group[item];
   const int m0 = a.item_m0[item], m1 = a.item_m1[item];
   const i32x4 rsrc = make_rsrc(a.X, BIGX ? 0u : uint32_t(a.x_bytes));
@@ -420,7 +496,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
     }
   }
 
-  const int out = a.item_out[item];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = a.grows[g * R + r];
@@ -632,7 +707,16 @@ int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32
   hipLaunchKernelGGL(k_item_copy, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.item_group, p.item_m0,
                      p.item_m1, p.item_out, w.itmp);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_item_permute, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.counts, w.ikey_b, w.itmp,
+  hipLaunchKernelGGL(k_item_len, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.counts, w.ikey_b, w.itmp, w.ilen);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::inclusive_scan(w.prim, pb, w.ilen, w.icum, size_t(p.cap_items), rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_xcd_bounds, dim3(1), dim3(64), 0, st, w.icum, p.counts, w.xbound, R, nnz);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_item_fill, blocks(p.cap_slots), dim3(T), 0, st, p.cap_slots, p.item_group, p.item_m0, p.item_m1,
+                     p.item_out);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_item_deal, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.counts, w.ikey_b, w.itmp, w.xbound,
                      p.item_group, p.item_m0, p.item_m1, p.item_out);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
@@ -659,7 +743,7 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   if (!rg_layout(F, &V, &C)) return fail(SGNN_ERR_UNSUPPORTED, "F too wide for the row-group kernel");
   Plan p = carve_plan(const_cast<void*>(plan), n_rows, nnz, R);
   if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "row-group plan buffer too small");
-  if (items <= 0 || items > p.cap_items || slots < 0 || n_long < 0 || n_long > p.cap_long)
+  if (items <= 0 || items > p.cap_slots || slots < 0 || n_long < 0 || n_long > p.cap_long)
     return fail(SGNN_ERR_INVALID, "item counts do not match the plan");
   if (slots > 0 && (!workspace || workspace_bytes < sgnn_spmm_rowgroup_workspace_bytes(slots, R, F)))
     return fail(SGNN_ERR_WORKSPACE, "row-group spmm workspace too small");
