@@ -57,7 +57,8 @@ int sgnn_version(void);
 /* Override a kernel-selection policy for experiments (process-wide, not thread
  * safe).  Keys: "tile" = feature-slice width in floats owned by one wavefront,
  * "unroll" = row fetches issued back to back (2 or 4), "rg_seg" = merged columns per
- * row-group work item, "rg_R" = rows per group, 8 or 16 (both affect plans built afterwards); value 0 restores the
+ * row-group work item, "rg_R" = rows per group, 8 or 16, "rg_order" = width of the column blocks the work
+ * items are ordered by (all three affect plans built afterwards); value 0 restores the
  * built-in policy.  No reference counterpart. */
 int sgnn_tune_set(const char* key, int value);
 

@@ -28,6 +28,7 @@ int fail(int code, const std::string& msg);
 
 // tuning hook: merged columns per row-group work item for plans built afterwards (0 = policy)
 void set_rowgroup_segment(int cols);
+void set_rowgroup_order(int cols);   // column-block width the work items are ordered by (0 = default)
 void set_rowgroup_R(int R);   // 8 or 16: group size for plans built afterwards (0 = policy)
 
 #define HIP_TRY(expr)                                                                         \

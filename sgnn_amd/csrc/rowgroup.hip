@@ -247,13 +247,13 @@ __global__ void k_items(int64_t G, int kSegCols, const int32_t* __restrict__ gpt
 // Order the work items by the column block their merged list starts in (ties: build
 // order).  Wavefronts that run at the same time then walk the same region of X, and
 // most of their row fetches hit the XCD's L2 instead of going to the Infinity Cache.
-constexpr int kOrderCols = 4096;
+int g_order_cols = 4096;   // sgnn_tune_set("rg_order", v)
 
 __global__ void k_item_keys(int64_t cap_items, const int64_t* __restrict__ counts, const int32_t* __restrict__ item_m0,
-                            const int32_t* __restrict__ gcol, uint64_t* __restrict__ keys) {
+                            const int32_t* __restrict__ gcol, int order_cols, uint64_t* __restrict__ keys) {
   int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (it >= cap_items) return;
-  keys[it] = it < counts[5] ? ((uint64_t(gcol[item_m0[it]] / kOrderCols) << 32) | uint64_t(it)) : ~uint64_t(0);
+  keys[it] = it < counts[5] ? ((uint64_t(gcol[item_m0[it]] / order_cols) << 32) | uint64_t(it)) : ~uint64_t(0);
 }
 
 __global__ void k_item_copy(int64_t cap_items, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
@@ -623,6 +623,7 @@ bool rg_layout(int64_t F, int* V, int* C) {
 namespace sgnn {
 void set_rowgroup_segment(int cols) { g_seg_override = cols; }
 void set_rowgroup_R(int R) { g_R_override = R; }
+void set_rowgroup_order(int cols) { g_order_cols = cols > 0 ? cols : 4096; }
 }  // namespace sgnn
 
 extern "C" {
@@ -700,7 +701,7 @@ int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32
   HIP_TRY(hipGetLastError());
   // launch order of the items
   hipLaunchKernelGGL(k_item_keys, blocks(p.cap_items), dim3(T), 0, st, p.cap_items, p.counts, p.item_m0, p.gcol,
-                     w.ikey_a);
+                     g_order_cols, w.ikey_a);
   HIP_TRY(hipGetLastError());
   pb = w.prim_bytes;
   HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.ikey_a, w.ikey_b, size_t(p.cap_items), 0u, 64u, st));

@@ -469,6 +469,7 @@ int sgnn_tune_set(const char* key, int value) {
   else if (!std::strcmp(key, "unroll")) g_tune.unroll = value;
   else if (!std::strcmp(key, "rg_seg")) sgnn::set_rowgroup_segment(value);
   else if (!std::strcmp(key, "rg_R")) sgnn::set_rowgroup_R(value);
+  else if (!std::strcmp(key, "rg_order")) sgnn::set_rowgroup_order(value);
   else return fail(SGNN_ERR_INVALID, std::string("unknown tuning key ") + key);
   return SGNN_OK;
 }
