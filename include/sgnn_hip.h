@@ -228,6 +228,17 @@ int sgnn_sample_block_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, co
                           const float* vals, int64_t b, const int64_t* idx, int flags,
                           float* out, int64_t ldo, void* stream);
 
+/*
+ * out[0:b] = the first b entries of a pseudo-random permutation of [0, n): distinct
+ * int64 node ids, as torch.randperm(n)[:b] gives the layers per optimiser iteration
+ * (model/SGNN.py:115-117), without sorting n keys.  `state` is uint64[2] in device
+ * memory, {seed, counter}; the call uses and then increments the counter on the
+ * stream, so a captured HIP graph that contains it draws a new batch on every
+ * replay.  The permutation is a 4-round Feistel network with cycle walking: a
+ * bijection for every (seed, counter), not a cryptographic one.
+ */
+int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,8 +27,9 @@ the reference:
   the GPU (``NormAdj.sample_block``) instead of scipy fancy indexing plus a
   host-to-device copy per iteration (model/SGNN.py:167-175).
 
-What differs, on purpose (these are the residency items the reference leaves on
-the table): features, targets and embeddings stay on the GPU instead of bouncing
+What differs, on purpose (these are the residency and launch-overhead items the
+reference leaves on the table): the Adam iterations of a layer run are captured once into
+a HIP graph and replayed (``_Layer._optimise``); features, targets and embeddings stay on the GPU instead of bouncing
 through host memory on every call (model/SGNN.py:404, 442-443), and ``A_hat^k X`` of a
 layer is computed once per distinct input instead of on every ``run`` — the first
 layer's input never changes, so 2*BP_count of its 2*BP_count+1 propagations
@@ -42,6 +43,7 @@ import numpy as np
 import torch
 import torch.nn.functional as Fn
 
+from . import _lib
 from . import utils as prop
 
 
@@ -108,6 +110,8 @@ class _Layer(torch.nn.Module):
         self.b = _glorot(1, embedding_dim, device)
         self.U = torch.nn.Parameter(torch.eye(input_dim, device=device), requires_grad=False)
         self.expected_X = None
+        self.use_graph = p.get("use_graph", True)
+        self._rng_state = None
         self._cache_in, self._cache_version, self._cache_val = None, -1, None
 
     def set_training_direction(self, is_backward, reset_backward=True):
@@ -129,14 +133,70 @@ class _Layer(torch.nn.Module):
             self._cache_in, self._cache_version = X, X._version
         return self._cache_val
 
-    def _ridge(self):
-        return self.W.pow(2).sum() + self.b.pow(2).sum() + self.U.pow(2).sum()
-
     def _lasso(self):
         return self.W.abs().sum() + self.b.abs().sum() + self.U.abs().sum()
 
     def _batch(self, rows):
-        return torch.randperm(rows, device=self.device)[:self.batch_size]
+        """Indices of a batch drawn without replacement: the head of a pseudo-random
+        permutation of ``range(rows)`` (model/SGNN.py:115-117 takes the head of
+        ``torch.randperm``), from ``sgnn_batch_indices`` — one small kernel instead of a
+        sort of ``rows`` keys, and it draws afresh on every replay of a HIP graph."""
+        if self._rng_state is None:      # seeded from torch's generator, so torch.manual_seed governs it
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+        b = min(self.batch_size, rows)
+        out = torch.empty(b, dtype=torch.int64, device=self.device)
+        _lib.check(_lib.load().sgnn_batch_indices(rows, b, _lib.ptr(self._rng_state), _lib.ptr(out),
+                                                  _lib.current_stream(self.device)))
+        return out
+
+    # Optimiser iterations recorded into one HIP graph and replayed.  An iteration is
+    # ~100 kernels of a few microseconds each; issued one by one from Python it takes
+    # 0.7-1.2 ms, nearly all of it launch overhead on the host.
+    GRAPH_WARMUP = 3
+
+    def _optimise(self, loss_fn, ridge=0.0):
+        """``max_iter`` Adam steps on ``loss_fn()`` with a fresh optimiser (model/SGNN.py:417).
+
+        ``ridge`` > 0 adds the penalty ``ridge * (|W|^2 + |b|^2 + |U|^2)`` of
+        model/SGNN.py:88-92 through its gradient ``2 * ridge * p``, which is what Adam's
+        (coupled) ``weight_decay`` adds to the gradient: the same update without the six
+        reduction kernels and their backward per iteration."""
+        use_graph = self.use_graph and self.device.type == "cuda" and self.max_iter > 2 * self.GRAPH_WARMUP
+        penalised = [self.W, self.b, self.U]
+        others = [q for q in self.parameters() if all(q is not t for t in penalised)]
+        groups = [dict(params=penalised, weight_decay=2.0 * ridge)]
+        if others:
+            groups.append(dict(params=others, weight_decay=0.0))
+        opt = torch.optim.Adam(groups, lr=self.lr, capturable=use_graph,
+                               fused=True if self.device.type == "cuda" else None)
+
+        def step():
+            loss = loss_fn()
+            loss.backward()
+            opt.step()
+
+        if not use_graph:
+            for _ in range(self.max_iter):
+                opt.zero_grad()
+                step()
+            return
+        # the first steps run eagerly on a side stream (they create the optimiser state
+        # and let the allocator settle), the rest replay one captured step
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(self.GRAPH_WARMUP):
+                opt.zero_grad(set_to_none=True)
+                step()
+        cur.wait_stream(side)
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for _ in range(self.max_iter - self.GRAPH_WARMUP - 1):
+            graph.replay()
 
     def _finish(self, X, PX):
         with torch.no_grad():
@@ -159,22 +219,21 @@ class EmbeddingLayer(_Layer):
             tX = PX[self.train_mask]
             tT = None if embedding_target is None else embedding_target[self.train_mask]
             tY = self.labels[self.train_mask]
-            opt = torch.optim.Adam([q for q in self.parameters()], lr=self.lr)
-            for _ in range(self.max_iter):
-                opt.zero_grad()
+
+            def loss_fn():
                 idx = self._batch(tX.shape[0])
                 emb = self(tX[idx])
                 if tT is None:
                     loss = Fn.cross_entropy(emb.matmul(self.Wt), tY[idx])
                 else:
                     loss = eta * (emb - tT[idx]).pow(2).sum() / emb.shape[0]
-                loss = loss + self.lam * self._ridge()
                 if embedding_target is not None:
                     jdx = self._batch(PX.shape[0])
                     e2 = self(PX[jdx])
                     loss = loss + eta * (e2 - embedding_target[jdx]).pow(2).sum() / e2.shape[0]
-                loss.backward()
-                opt.step()
+                return loss
+
+            self._optimise(loss_fn, ridge=self.lam)
         return self._finish(X, PX)
 
     @torch.no_grad()
@@ -221,9 +280,7 @@ class GAELayer(_Layer):
     def run(self, X, embedding_target=None, eta=1, train=True):
         PX = self.propagated(X)
         if train:
-            opt = torch.optim.Adam([q for q in self.parameters()], lr=self.lr)
-            for _ in range(self.max_iter):
-                opt.zero_grad()
+            def loss_fn():
                 idx = self._batch(PX.shape[0])
                 target = self.adjacency.sample_block(idx, skip_self=True)              # model/SGNN.py:167-170
                 emb = self(PX[idx])
@@ -231,8 +288,9 @@ class GAELayer(_Layer):
                 loss = loss + self.lam * self._lasso()
                 if embedding_target is not None:
                     loss = loss + eta * (emb - embedding_target[idx]).pow(2).sum() / emb.shape[0]
-                loss.backward()
-                opt.step()
+                return loss
+
+            self._optimise(loss_fn)
         return self._finish(X, PX)
 
 

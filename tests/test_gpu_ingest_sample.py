@@ -111,3 +111,43 @@ def test_sample_block_reddit_batch_density(gpu_device):
     i = idx.cpu().numpy()
     exp = orc.sample_block(orc.remove_self_loop(A), i)
     assert np.array_equal(blk.cpu().numpy(), exp)
+
+
+def test_batch_indices_are_a_permutation_head(gpu_device):
+    """sgnn_batch_indices stands in for torch.randperm(n)[:b] (model/SGNN.py:115-117):
+    distinct ids in range, a full permutation when b = n, a new draw per call, the same
+    draw for the same (seed, counter), and no position or id favoured."""
+    from sgnn_amd import _lib
+    lib = _lib.load()
+
+    def draw(n, b, state):
+        out = torch.empty(b, dtype=torch.int64, device=gpu_device)
+        _lib.check(lib.sgnn_batch_indices(n, b, _lib.ptr(state), _lib.ptr(out), _lib.current_stream(gpu_device)))
+        return out.cpu().numpy()
+
+    for n in (1, 2, 5, 64, 1000, 4097, 232_965):
+        state = torch.tensor([12345 + n, 0], dtype=torch.int64, device=gpu_device)
+        full = draw(n, n, state)
+        assert np.array_equal(np.sort(full), np.arange(n)), n
+        assert int(state[1]) == 1
+        again = draw(n, n, state)
+        if n > 64:
+            assert not np.array_equal(full, again)
+        state2 = torch.tensor([12345 + n, 0], dtype=torch.int64, device=gpu_device)
+        assert np.array_equal(draw(n, min(n, 17), state2), full[:min(n, 17)])
+    # uniformity: 2000 batches of 512 from 10 000 ids, every id expected 102.4 times
+    n, b, reps = 10_000, 512, 2000
+    state = torch.tensor([7, 0], dtype=torch.int64, device=gpu_device)
+    counts = np.zeros(n, np.int64)
+    first = np.zeros(n, np.int64)
+    for _ in range(reps):
+        d = draw(n, b, state)
+        assert np.unique(d).size == b
+        counts[d] += 1
+        first[d[0]] += 1
+    expected = reps * b / n
+    chi2 = float(((counts - expected) ** 2 / expected).sum())
+    assert abs(chi2 - n) < 6 * np.sqrt(2 * n), chi2          # chi-square with ~n degrees of freedom
+    assert first.max() <= 6                                    # no id owns the first slot
+    with pytest.raises(_lib.SgnnHipError):
+        draw(5, 6, state)

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=10000)
     ap.add_argument("--workload", default="reddit")
     ap.add_argument("--task", default="classification", choices=["classification", "clustering"])
+    ap.add_argument("--no-graph", action="store_true", help="issue every optimiser iteration from Python")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     n, E, F = SHAPES[args.workload]
@@ -49,11 +50,11 @@ def main():
     if clustering:
         layers = [LayerParam(nn_, inner_act=get_activation("relu"), act=get_activation("linear"),
                              gnn_type=LayerParam.GAE, mask_rate=0.2, learning_rate=1e-4, max_iter=args.max_iter,
-                             lam=1e-6, batch_size=512) for nn_ in (128, 64)]
+                             lam=1e-6, batch_size=512, use_graph=not args.no_graph) for nn_ in (128, 64)]
     else:
         layers = [LayerParam(nn_, inner_act=get_activation("leaky_relu=0.2"), act=get_activation("linear"),
                              gnn_type=LayerParam.EGCN, learning_rate=1e-4, max_iter=args.max_iter, lam=1e-6,
-                             batch_size=512) for nn_ in (128, 64)]
+                             batch_size=512, use_graph=not args.no_graph) for nn_ in (128, 64)]
     # assemble the stacked model around the prebuilt handle (its constructor takes scipy; skip that path)
     cls = StackedGNN if clustering else SupervisedStackedGNN
     model = cls.__new__(cls)
@@ -88,7 +89,7 @@ def main():
     torch.cuda.synchronize(); t_epoch = time.perf_counter() - t0
     ms_all = [a.elapsed_time(b) for a, b in prop_ms]
     iters_epoch = 4 * args.max_iter
-    out = {"workload": args.workload, "task": args.task, "max_iter": args.max_iter,
+    out = {"workload": args.workload, "task": args.task, "hip_graph": not args.no_graph, "max_iter": args.max_iter,
            "first_forward_sweep_s": round(t_fwd0, 3), "epoch_s": round(t_epoch, 3),
            "s_per_iteration": t_epoch / iters_epoch,
            "propagations_first_sweep": n0, "propagations_in_epoch": len(ms_all) - n0,
