@@ -158,7 +158,7 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * Row-group form of a unit-weight CSR, and the SpMM kernel that uses it.
+ * Row-group form of a CSR's sparsity pattern, and the SpMM kernel that uses it.
  *
  * Rows are ranked by degree and cut into groups of R (8 or 16); a group stores
  * one merged column list with an R-bit mask per column.  The kernel fetches each
@@ -173,9 +173,13 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                        (0: this F is not supported, use sgnn_spmm_csr_f32)
  * sgnn_rowgroup_build    fills `plan` (device, sgnn_rowgroup_plan_bytes) from the
  *                        CSR; when the stream has drained, the first four int64
- *                        of `plan` hold {merged entries, work items, partial
+ *                        of `plan` hold {merged entries, launch slots, partial
  *                        slots, split groups} — the caller reads them once and
- *                        passes the last three to every SpMM call
+ *                        passes the last three to every SpMM call as items, slots,
+ *                        n_long.  Launch slots are the work items laid out for the
+ *                        grid: on graphs whose rows share columns the items are dealt
+ *                        to the 8 XCDs in contiguous, work-balanced runs padded to
+ *                        equal length, so the count can exceed the item count.
  * sgnn_spmm_rowgroup_f32 workspace >= sgnn_spmm_rowgroup_workspace_bytes(slots, R, F).
  *                        The plan stores the sparsity pattern only.  An adjacency whose
  *                        off-diagonal entries all carry one weight w_off (Reddit's A + A^T

@@ -11,9 +11,11 @@
 // floats per lane, all in registers).  On the Reddit-shape benchmark graph the
 // merged lists hold 49 % (R = 16) of the entries, and the kernel time follows.
 //
-// Reference path served: the adj.mm of utils.py:94 for unit-weight adjacencies
-// (every dataset loader of the reference builds those, data_loader.py:545-549;
-// weighted graphs take the plain CSR kernel).
+// Reference path served: the adj.mm of utils.py:94 for adjacencies whose
+// off-diagonal entries all carry one weight (the 0/1 matrices of the reference's
+// loaders, data_loader.py:545-549, and Reddit's weight-2 A + A^T, data_loader.py:75):
+// the masks carry no values, the epilogue applies the weight and the diagonal
+// correction.  Other weighted graphs take the plain CSR kernel.
 #include <cstring>  // rocprim's texture iterator calls memset from host code
 
 #include <rocprim/rocprim.hpp>
