@@ -379,6 +379,11 @@ __device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t col
 }
 
 // Add the fetched rows into the accumulators of the rows whose mask bit is set.
+// Two thirds of the merged columns belong to a single row of their group, so the R
+// bit tests are guarded four at a time: an empty nibble costs one test, not four.
+// (Walking the set bits with find-first-set and a compare tree down to the statically
+// indexed accumulator was tried: the compiler folds the tree's leaves into one
+// dynamically indexed access and moves the accumulators to scratch memory.)
 template <int R, int V, int C, int UU, bool HASD>
 __device__ __forceinline__ void rg_accum(uint32_t masks, float ws, int k, const float (&xv)[UU][C][V],
                                          float (&acc)[R][C][V]) {
@@ -388,14 +393,18 @@ __device__ __forceinline__ void rg_accum(uint32_t masks, float ws, int k, const 
     float w = 1.0f;
     if constexpr (HASD) w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), k + u));
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (mk & (1u << r)) {   // wave-uniform: a scalar bit test and branch
+    for (int q = 0; q < R; q += 4)
+      if (mk & (0xFu << q)) {   // wave-uniform: scalar tests and branches throughout
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+        for (int r = q; r < q + 4; ++r)
+          if (mk & (1u << r)) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            if constexpr (HASD) acc[r][c][v] = fmaf(w, xv[u][c][v], acc[r][c][v]);
-            else acc[r][c][v] += xv[u][c][v];
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                if constexpr (HASD) acc[r][c][v] = fmaf(w, xv[u][c][v], acc[r][c][v]);
+                else acc[r][c][v] += xv[u][c][v];
+              }
           }
       }
   }
