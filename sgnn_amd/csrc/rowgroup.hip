@@ -383,7 +383,8 @@ __device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t col
 // bit tests are guarded four at a time: an empty nibble costs one test, not four.
 // (Walking the set bits with find-first-set and a compare tree down to the statically
 // indexed accumulator was tried: the compiler folds the tree's leaves into one
-// dynamically indexed access and moves the accumulators to scratch memory.)
+// dynamically indexed access and moves the accumulators to scratch memory; with the
+// fold blocked the kernel needs 386 registers, one wavefront per SIMD.)
 template <int R, int V, int C, int UU, bool HASD>
 __device__ __forceinline__ void rg_accum(uint32_t masks, float ws, int k, const float (&xv)[UU][C][V],
                                          float (&acc)[R][C][V]) {
