@@ -8,9 +8,13 @@ config.json:480-503, GNN_tasks.py:76-80).
 
 One step = one call of ``process_data_with_adjacency_high_order`` on a prebuilt
 adjacency handle with X resident in HBM.  Rank 0 prints ONE JSON line.
-N > 1 (launched by torch.distributed.run, one rank per GPU) partitions the rows
-of the same graph over the ranks (strong scaling) and all-gathers the scaled
-row blocks of X over RCCL before each rank's SpMM.
+N > 1 (launched by torch.distributed.run, one rank per GPU) splits the same job
+over the ranks (strong scaling) on a feature_groups x row_ranks grid: a rank owns a
+block of rows of the graph and a slice of the feature columns, and all-gathers the
+scaled row blocks of its slice over RCCL before its SpMM.  Feature slices need no
+exchange at all, row blocks keep the rows wide; which grid is fastest depends on
+the xGMI all-gather rate, so with ``--feature-groups 0`` (default) every grid that
+divides N is timed for a few untimed steps and the fastest is benchmarked.
 """
 from __future__ import annotations
 
@@ -85,6 +89,8 @@ def main():
     ap.add_argument("--max-degree", type=int, default=None, help="clip hub degree (real Reddit's is ~21.7k)")
     ap.add_argument("--slices", type=int, default=2,
                     help="N > 1: feature slices of the exchange/SpMM pipeline (1 = no overlap)")
+    ap.add_argument("--feature-groups", type=int, default=0,
+                    help="N > 1: ranks per row block that split the feature columns (0 = time every divisor of N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-edges", type=int, default=10_000_000)
     args = ap.parse_args()
@@ -101,10 +107,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # Rehearsal on a one-GPU box: SGNN_BENCH_REHEARSAL=1 puts every rank on cuda:0 and
+    # exchanges through gloo (host-staged), to exercise the N > 1 code path without RCCL.
+    rehearsal = world > 1 and os.environ.get("SGNN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     n, E, F = SHAPES[args.workload]
     t0 = time.perf_counter()
@@ -126,38 +140,76 @@ def main():
         step = lambda: adj.propagate(X, args.order)          # noqa: E731
         max_deg = int((adj.rowptr[1:] - adj.rowptr[:-1]).max().item())
     else:
-        from sgnn_amd.dist import PartitionedAdj
-        t0 = time.perf_counter()
-        padj = PartitionedAdj.from_coo(row, col, None, n, device, rank, world)
-        torch.cuda.synchronize()
-        extra["adjacency_build_ms"] = (time.perf_counter() - t0) * 1e3
-        del row, col
-        nnz = padj.global_nnz
-        Xl = X[padj.row_begin:padj.row_end].contiguous()
-        del X
-        # the overlapped (feature-sliced) schedule is used only if it reproduces the
-        # plain one on this machine; every rank takes the same decision
-        slices = max(1, args.slices)
-        if slices > 1:
+        from sgnn_amd.dist import PartitionedAdj, grid_layout, make_row_groups
+
+        def build_grid(fg):
+            """Everything one candidate grid needs: (step function, info)."""
+            row_rank, row_world, fgroup, f0, f1 = grid_layout(rank, world, fg, F)
+            group = make_row_groups(world, fg)
+            t0 = time.perf_counter()
+            padj = PartitionedAdj.from_coo(row, col, None, n, device, row_rank, row_world, group=group)
+            torch.cuda.synchronize()
+            build_ms = (time.perf_counter() - t0) * 1e3
+            Xl = X[padj.row_begin:padj.row_end, f0:f1].contiguous()
+            # the overlapped (feature-sliced) exchange is used only if it reproduces the
+            # plain one on this machine; every rank of the job takes the same decision
+            slices = max(1, args.slices) if row_world > 1 else 1
             ok = torch.ones(1, device=device)
-            try:
-                a = padj.propagate(Xl, args.order, slices=1)
-                b = padj.propagate(Xl, args.order, slices=slices)
-                if not torch.allclose(a, b, rtol=1e-4, atol=1e-5):
+            if slices > 1:
+                try:
+                    a = padj.propagate(Xl, args.order, slices=1)
+                    b = padj.propagate(Xl, args.order, slices=slices)
+                    if not torch.allclose(a, b, rtol=1e-4, atol=1e-5):
+                        ok.zero_()
+                    del a, b
+                except Exception as exc:          # noqa: BLE001
+                    print(f"[rank {rank}] sliced schedule failed: {exc}", file=sys.stderr, flush=True)
                     ok.zero_()
-                del a, b
-            except Exception as exc:          # noqa: BLE001
-                print(f"[rank {rank}] sliced schedule failed: {exc}", file=sys.stderr, flush=True)
-                ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if ok.item() == 0:
                 slices = 1
-        extra["exchange_slices"] = slices
-        step = lambda: padj.propagate(Xl, args.order, slices=slices)        # noqa: E731
-        max_deg = padj.global_max_degree
+            info = {"feature_groups": fg, "row_ranks": row_world, "features_per_rank": f1 - f0,
+                    "exchange_slices": slices,
+                    "adjacency_build_ms": build_ms, "nnz": padj.global_nnz, "max_deg": padj.global_max_degree}
+            return (lambda: padj.propagate(Xl, args.order, slices=slices)), info
+
+        def probe(step_fn, reps=3):
+            for _ in range(2):
+                step_fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step_fn()
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / reps], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        if args.feature_groups > 0:
+            candidates = [args.feature_groups]
+        else:
+            candidates = [g for g in range(1, world + 1) if world % g == 0 and g <= F]
+        best = None
+        probed = {}
+        for fg in candidates:
+            step_fn, info = build_grid(fg)
+            t = probe(step_fn) if len(candidates) > 1 else 0.0
+            probed[str(fg)] = round(t * 1e3, 3)
+            if best is None or t < best[0]:
+                best = (t, step_fn, info)
+            else:
+                del step_fn
+            torch.cuda.empty_cache()
+        _, step, info = best
+        del row, col, X
+        nnz, max_deg = info.pop("nnz"), info.pop("max_deg")
+        extra.update(info)
+        if len(candidates) > 1:
+            extra["grid_probe_ms"] = probed
 
     lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
-    R = lib.sgnn_rowgroup_config(F)
+    R = lib.sgnn_rowgroup_config(extra.get("features_per_rank", F))
     kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
     for _ in range(args.warmup):
         step()
@@ -204,10 +256,12 @@ def main():
             "config": {
                 "workload": f"{args.workload}-shape symmetric R-MAT(0.57,0.19,0.19,0.05): n={n}, "
                             f"nnz(A+I)={nnz}, F={F}, order={args.order}, max_degree={max_deg}, unit weights",
-                "rows": "one GPU" if world == 1 else f"row-partitioned over {world} GPUs, all-gather of scaled X blocks",
+                "rows": "one GPU" if world == 1 else
+                        f"{extra['feature_groups']} feature slices x {extra['row_ranks']} row blocks over {world} GPUs, "
+                        "all-gather of scaled X blocks inside a feature slice",
                 "graph_gen_s": round(t_gen, 2),
                 "kernel": kernel_path,
-                **{k: round(v, 2) for k, v in extra.items()},
+                **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in extra.items()},
             },
             "roofline": {
                 "bound": "hbm",

@@ -18,6 +18,14 @@ remapped once into the padded index space.  Pre-scaling before the exchange mean
 ``dinv`` itself never travels.  With ``slices > 1`` the feature dimension is cut
 into column slices and the all-gather of slice s+1 runs on a side stream while
 slice s is multiplied, which hides most of the exchange behind the SpMM.
+
+The columns of X are independent, so the feature dimension can be split over ranks
+with no exchange at all.  ``grid_layout`` arranges the ranks as ``feature_groups`` x
+``row_ranks``: a rank owns one block of rows and one slice of features, and the
+all-gather above runs only among the ranks that share its feature slice
+(``make_row_groups`` builds those sub-groups).  ``feature_groups == world`` needs no
+communication; 1 is the pure row partition; values in between trade the exchange
+volume (halved per doubling) against narrower, less efficient rows per rank.
 """
 from __future__ import annotations
 
@@ -27,6 +35,47 @@ import torch.distributed as dist
 
 from . import _lib
 from .norm_adj import NormAdj
+
+
+def grid_layout(rank, world, feature_groups, F, align=2):
+    """Place ``rank`` on a ``feature_groups`` x ``world // feature_groups`` grid:
+    consecutive ranks share a feature slice (and exchange rows with each other).
+    Returns ``(row_rank, row_world, fgroup, f0, f1)``; slice boundaries are multiples
+    of ``align`` floats where F allows, so that vector loads stay usable."""
+    if feature_groups < 1 or world % feature_groups:
+        raise ValueError(f"feature_groups={feature_groups} does not divide world={world}")
+    if feature_groups > F:
+        raise ValueError("more feature groups than features")
+    row_world = world // feature_groups
+    fgroup, row_rank = divmod(rank, row_world)
+
+    def cut(k):
+        if k == 0 or k == feature_groups:
+            return 0 if k == 0 else F
+        c = F * k // feature_groups
+        a = (c + align // 2) // align * align
+        return a if F * (k - 1) // feature_groups < a < F else c
+    cuts = [cut(k) for k in range(feature_groups + 1)]
+    if any(b <= a for a, b in zip(cuts, cuts[1:])):           # tiny F: fall back to unaligned cuts
+        cuts = [F * k // feature_groups for k in range(feature_groups + 1)]
+    return row_rank, row_world, fgroup, cuts[fgroup], cuts[fgroup + 1]
+
+
+def make_row_groups(world, feature_groups):
+    """Process group of the ranks that share this rank's feature slice (collective:
+    every rank must call it, with the same arguments).  ``None`` when the default
+    group already is that set (``feature_groups == 1``) or when the rank exchanges
+    with nobody (``feature_groups == world``)."""
+    row_world = world // feature_groups
+    if feature_groups == 1 or row_world == 1:
+        return None
+    mine, rank = None, dist.get_rank()
+    for g in range(feature_groups):
+        ranks = list(range(g * row_world, (g + 1) * row_world))
+        grp = dist.new_group(ranks)                             # every rank creates every group, in order
+        if rank in ranks:
+            mine = grp
+    return mine
 
 
 def balanced_row_splits(counts, world):

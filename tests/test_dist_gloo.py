@@ -93,6 +93,74 @@ def test_row_partitioned_matches_single(world, order):
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
 
 
+def _grid_worker(rank, world, fg, port, n, r, c, X, order, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgnn_amd.dist import PartitionedAdj, grid_layout, make_row_groups
+        row_rank, row_world, fgroup, f0, f1 = grid_layout(rank, world, fg, X.shape[1])
+        group = make_row_groups(world, fg)
+        padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, "cpu", row_rank, row_world,
+                                       group=group, local_factory=OracleBlock)
+        Xl = torch.from_numpy(X[padj.row_begin:padj.row_end, f0:f1].copy())
+        Y = padj.propagate(Xl, order)
+        q.put((rank, padj.row_begin, padj.row_end, f0, f1, Y.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fg,order", [(4, 2, 2), (2, 2, 1), (3, 1, 1)])
+def test_feature_by_row_grid_matches_single(world, fg, order):
+    """Ranks on a feature_groups x row_ranks grid: every (row block, feature slice)
+    tile is produced exactly once and the assembled result is the single-process one."""
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    import scipy.sparse as sp
+    n, F = 500, 10
+    r, c = symmetric_simple_numpy(n, 3000, seed=4)
+    X = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
+    exp = orc.propagate_scipy(sp.coo_matrix((np.ones(r.size, np.float32), (r, c)), shape=(n, n)), X, order)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(k, world, fg, port, n, r, c, X, order, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Y = np.zeros_like(exp)
+    covered = np.zeros((n, F), np.int32)
+    for rank, r0, r1, f0, f1, y in got:
+        Y[r0:r1, f0:f1] = y
+        covered[r0:r1, f0:f1] += 1
+    assert (covered == 1).all()
+    assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
+
+
+def test_grid_layout_slices():
+    from sgnn_amd.dist import grid_layout
+    for world, fg, F in [(8, 2, 602), (8, 8, 602), (4, 4, 128), (8, 4, 100), (2, 2, 3), (6, 3, 7)]:
+        seen = []
+        for rank in range(world):
+            row_rank, row_world, fgroup, f0, f1 = grid_layout(rank, world, fg, F)
+            assert row_world == world // fg and 0 <= row_rank < row_world and rank == fgroup * row_world + row_rank
+            assert 0 <= f0 < f1 <= F
+            if row_rank == 0:
+                seen.append((f0, f1))
+        assert seen[0][0] == 0 and seen[-1][1] == F
+        assert all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+        widths = [b - a for a, b in seen]
+        assert max(widths) - min(widths) <= 2
+        if F % 2 == 0 and F >= 4 * fg:
+            assert all(a % 2 == 0 for a, _ in seen)
+    assert grid_layout(5, 8, 2, 602) == (1, 4, 1, 302, 602)
+    with pytest.raises(ValueError):
+        grid_layout(0, 8, 3, 602)
+
+
 def test_balanced_splits_and_padding():
     from sgnn_amd.dist import balanced_row_splits, pad_index_map
     counts = np.array([100, 1, 1, 1, 1, 50, 50, 1, 1, 1])
