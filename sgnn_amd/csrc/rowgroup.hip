@@ -17,6 +17,7 @@
 // the masks carry no values, the epilogue applies the weight and the diagonal
 // correction.  Other weighted graphs take the plain CSR kernel.
 #include <cstring>  // rocprim's texture iterator calls memset from host code
+#include <type_traits>
 
 #include <rocprim/rocprim.hpp>
 
@@ -352,29 +353,57 @@ struct RgArgs {
   const int32_t *grows, *gptr, *gcol;
   const uint32_t* gmask;
   const int32_t *item_group, *item_m0, *item_m1, *item_out, *long_group, *long_slot;
-  const float *dinv_row, *dinv_col, *X, *corr;
+  const float *dinv_row, *X, *corr;
   float *Y, *partial;
   int64_t ldx, ldy, x_bytes, x_row_offset;
   float w_off;
   int32_t items, n_long, F, row_bytes, y_vec, epilogue, seg;
 };
 
+// ---- feature layout ------------------------------------------------------------------
+// A lane owns NF = 4*C4 + 2*C2 + C1 features of every accumulated row: C4 chunks of
+// 256 features read with one 16-byte load per lane, then C2 chunks of 128 (8-byte
+// loads), then C1 chunks of 64 (4-byte loads).  Measured on the Reddit shape: a row
+// fetch costs ~2.5 ms per 16-byte chunk (1 KiB per wavefront instruction) against
+// ~1.7 ms per 8-byte chunk (512 B), so the wide loads carry as much of the row as the
+// register budget allows and the narrower ones only its tail.  Rows of X must start on
+// 16-byte boundaries (X 16-byte aligned, ldx a multiple of 4).
+template <int C4, int C2, int C1>
+struct Lay {
+  static constexpr int NF = 4 * C4 + 2 * C2 + C1;
+  static constexpr int kOff2 = C4 * 256;             // first feature of the 8-byte chunks
+  static constexpr int kOff1 = C4 * 256 + C2 * 128;  // first feature of the 4-byte chunks
+};
+
 // Issue the fetches of UU consecutive merged columns (lanes k .. k+UU-1 of `cols`).
-template <int V, int C, int UU, bool BIGX>
-__device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t cols, int k, const int (&boff)[C],
-                                        float (&xv)[UU][C][V]) {
+template <class L, int C4, int C2, int C1, int UU, bool BIGX>
+__device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t cols, int k, int lane,
+                                        float (&xv)[UU][L::NF]) {
 #pragma unroll
   for (int u = 0; u < UU; ++u) {
     const int32_t col = __builtin_amdgcn_readlane(cols, k + u);
+    i32x4 rr = rsrc;
+    int soff = 0;
     if constexpr (BIGX) {   // X spans 4 GiB or more: re-base the descriptor on the fetched row
-      const i32x4 rr = make_rsrc(a.X + int64_t(col) * a.ldx, uint32_t(a.F) * 4u);
-#pragma unroll
-      for (int c = 0; c < C; ++c) buffer_load_vec<V>(rr, boff[c], 0, xv[u][c]);
+      rr = make_rsrc(a.X + int64_t(col) * a.ldx, uint32_t(a.F) * 4u);
     } else {
-      const int soff = col * a.row_bytes;
-#pragma unroll
-      for (int c = 0; c < C; ++c) buffer_load_vec<V>(rsrc, boff[c], soff, xv[u][c]);
+      soff = col * a.row_bytes;
     }
+#pragma unroll
+    for (int c = 0; c < C4; ++c) {
+      const f32x4 x = raw_buffer_load_f32x4(rr, lane * 16 + c * 1024, soff, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[u][4 * c + j] = x[j];
+    }
+#pragma unroll
+    for (int c = 0; c < C2; ++c) {
+      const f32x2 x = raw_buffer_load_f32x2(rr, lane * 8 + (L::kOff2 + c * 128) * 4, soff, 0);
+      xv[u][4 * C4 + 2 * c] = x[0];
+      xv[u][4 * C4 + 2 * c + 1] = x[1];
+    }
+#pragma unroll
+    for (int c = 0; c < C1; ++c)
+      xv[u][4 * C4 + 2 * C2 + c] = raw_buffer_load_f32(rr, lane * 4 + (L::kOff1 + c * 64) * 4, soff, 0);
   }
 }
 
@@ -385,14 +414,11 @@ __device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t col
 // indexed accumulator was tried: the compiler folds the tree's leaves into one
 // dynamically indexed access and moves the accumulators to scratch memory; with the
 // fold blocked the kernel needs 386 registers, one wavefront per SIMD.)
-template <int R, int V, int C, int UU, bool HASD>
-__device__ __forceinline__ void rg_accum(uint32_t masks, float ws, int k, const float (&xv)[UU][C][V],
-                                         float (&acc)[R][C][V]) {
+template <int R, int NF, int UU>
+__device__ __forceinline__ void rg_accum(uint32_t masks, int k, const float (&xv)[UU][NF], float (&acc)[R][NF]) {
 #pragma unroll
   for (int u = 0; u < UU; ++u) {
     const uint32_t mk = uint32_t(__builtin_amdgcn_readlane(int(masks), k + u));
-    float w = 1.0f;
-    if constexpr (HASD) w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), k + u));
 #pragma unroll
     for (int q = 0; q < R; q += 4)
       if (mk & (0xFu << q)) {   // wave-uniform: scalar tests and branches throughout
@@ -400,12 +426,7 @@ __device__ __forceinline__ void rg_accum(uint32_t masks, float ws, int k, const 
         for (int r = q; r < q + 4; ++r)
           if (mk & (1u << r)) {
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-#pragma unroll
-              for (int v = 0; v < V; ++v) {
-                if constexpr (HASD) acc[r][c][v] = fmaf(w, xv[u][c][v], acc[r][c][v]);
-                else acc[r][c][v] += xv[u][c][v];
-              }
+            for (int i = 0; i < NF; ++i) acc[r][i] += xv[u][i];
           }
       }
   }
@@ -414,15 +435,13 @@ __device__ __forceinline__ void rg_accum(uint32_t masks, float ws, int k, const 
 // Row epilogue.  `s` is the pattern sum (every stored entry counted once).  For an
 // adjacency whose off-diagonal entries all carry the weight w_off and whose
 // diagonal entry of row i is d_i, the weighted sum is w_off*s + (d_i - w_off)*x'_i
-// (corr[i] = d_i - w_off, x' = the scaled row of X the kernel saw); unit-weight
-// graphs have w_off = 1 and corr = NULL.  Then the row scaling of utils.py:95.
+// (corr[i] = d_i - w_off, x' = the row of X the kernel saw); unit-weight graphs have
+// w_off = 1 and corr = NULL.  Then the row scaling of utils.py:95.
 __device__ __forceinline__ float rg_epilogue(const RgArgs& a, float s, int row, int f, bool scale, float dr) {
   float y = s;
   if (a.corr != nullptr) {
     const int64_t xr = int64_t(row) + a.x_row_offset;
-    float xs = a.X[xr * a.ldx + f];
-    if (a.dinv_col != nullptr) xs *= a.dinv_col[xr];
-    y = fmaf(a.w_off, y, a.corr[row] * xs);
+    y = fmaf(a.w_off, y, a.corr[row] * a.X[xr * a.ldx + f]);
   } else if (a.w_off != 1.0f) {
     y *= a.w_off;
   }
@@ -433,81 +452,38 @@ __device__ __forceinline__ float rg_epilogue(const RgArgs& a, float s, int row, 
   return y;
 }
 
-// One wavefront per work item; lane l owns features (c*64 + l)*V .. +V of all R
-// accumulated rows.  Merged columns are taken 64 at a time through a VGPR (ids,
-// masks and, with HASD, dinv[col]) and handed to the scalar unit by v_readlane;
-// every row of a group is summed in ascending column order.
-template <int R, int V, int C, int U, bool HASD, bool BIGX>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
-  const int lane = threadIdx.x & (kWave - 1);
-  // Launch slots are laid out so that the workgroups of one XCD walk one contiguous,
-  // work-balanced stretch of the column-ordered item list (k_item_deal).
-  const int item = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * kWavesPerBlock + int(threadIdx.x) / kWave);
-  if (item >= a.items) return;
-  const int out = a.item_out[item];
-  if (out < -1) return;   // padding slot
-  const int g = a.item_group[item];
-  const int m0 = a.item_m0[item], m1 = a.item_m1[item];
-  const i32x4 rsrc = make_rsrc(a.X, BIGX ? 0u : uint32_t(a.x_bytes));
-  int boff[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) boff[c] = (c * kWave + lane) * V * 4;
-  float acc[R][C][V];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-      for (int v = 0; v < V; ++v) acc[r][c][v] = 0.0f;
-
-  int32_t ncols = 0;
-  uint32_t nmask = 0;
-  float nws = 0.0f;
-  if (m0 + lane < m1) {
-    ncols = a.gcol[m0 + lane];
-    nmask = a.gmask[m0 + lane];
-    if constexpr (HASD) nws = a.dinv_col[ncols];
-  }
-  // Two fetch buffers: while the rows of one step are added, the fetches of the
-  // following step are already in flight (also across the 64-column batches).
-  // Invariant at the top of a batch: xa holds the batch's step 0 iff the batch has
-  // at least U columns.  Every batch but an item's last is full and 64 / U is even,
-  // so an odd number of full steps can only occur in the last batch.
-  float xa[U][C][V], xb[U][C][V];
-  if (min(kWave, m1 - m0) >= U) rg_load<V, C, U, BIGX>(a, rsrc, ncols, 0, boff, xa);
-  for (int m = m0; m < m1; m += kWave) {
-    const int32_t cols = ncols;
-    const uint32_t masks = nmask;
-    const float ws = nws;
-    const int cnt = min(kWave, m1 - m);
-    const bool more = m + kWave < m1;
-    const bool mine = m + kWave + lane < m1;
-    if (more) {
-      ncols = mine ? a.gcol[m + kWave + lane] : 0;
-      nmask = mine ? a.gmask[m + kWave + lane] : 0u;
-      if constexpr (HASD) nws = mine ? a.dinv_col[ncols] : 0.0f;
-    }
-    const int nfull = cnt / U * U;
-    const bool next_full_step = more && (m1 - (m + kWave)) >= U;
-    int k = 0;
-    for (; k + 2 * U <= nfull; k += 2 * U) {
-      rg_load<V, C, U, BIGX>(a, rsrc, cols, k + U, boff, xb);
-      rg_accum<R, V, C, U, HASD>(masks, ws, k, xa, acc);
-      if (k + 2 * U < nfull) rg_load<V, C, U, BIGX>(a, rsrc, cols, k + 2 * U, boff, xa);
-      else if (next_full_step) rg_load<V, C, U, BIGX>(a, rsrc, ncols, 0, boff, xa);
-      rg_accum<R, V, C, U, HASD>(masks, ws, k + U, xb, acc);
-    }
-    if (k < nfull) {   // odd count of full steps: last batch only, xa holds the step
-      rg_accum<R, V, C, U, HASD>(masks, ws, k, xa, acc);
-      k += U;
-    }
-    for (; k < cnt; ++k) {
-      float x1[1][C][V];
-      rg_load<V, C, 1, BIGX>(a, rsrc, cols, k, boff, x1);
-      rg_accum<R, V, C, 1, HASD>(masks, ws, k, x1, acc);
+// store V consecutive features f .. f+V-1 of one output row (those below F)
+template <int V>
+__device__ __forceinline__ void rg_store(const RgArgs& a, float* dst, const float* o, int f, int aligned_for) {
+  if (f + V <= a.F) {
+    if constexpr (V == 4) {
+      if (aligned_for >= 4) {
+        *reinterpret_cast<f32x4*>(dst + f) = f32x4{o[0], o[1], o[2], o[3]};
+        return;
+      }
+      if (aligned_for >= 2) {
+        *reinterpret_cast<f32x2*>(dst + f) = f32x2{o[0], o[1]};
+        *reinterpret_cast<f32x2*>(dst + f + 2) = f32x2{o[2], o[3]};
+        return;
+      }
+    } else if constexpr (V == 2) {
+      if (aligned_for >= 2) {
+        *reinterpret_cast<f32x2*>(dst + f) = f32x2{o[0], o[1]};
+        return;
+      }
     }
   }
+#pragma unroll
+  for (int j = 0; j < V; ++j)
+    if (f + j < a.F) dst[f + j] = o[j];
+}
 
+// Write a wavefront's R accumulated rows: straight to Y through the epilogue when the
+// group has a single work item (out < 0), else as partial rows into slot `out`.
+template <int R, int C4, int C2, int C1>
+__device__ __forceinline__ void rg_write_rows(const RgArgs& a, const float (&acc)[R][Lay<C4, C2, C1>::NF], int g,
+                                              int out, int lane) {
+  using L = Lay<C4, C2, C1>;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = a.grows[g * R + r];
@@ -525,18 +501,94 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
       dst = a.partial + (int64_t(out) * R + r) * a.F;
       aligned_for = (a.F % 4 == 0) ? 4 : (a.F % 2 == 0 ? 2 : 1);
     }
+    auto put = [&](auto vtag, int f, const float* s) {
+      constexpr int V = decltype(vtag)::value;
+      if (f >= a.F) return;
+      float o[V];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int f = (c * kWave + lane) * V;
-      if (f < a.F) {
-        float o[V];
+      for (int j = 0; j < V; ++j)
+        o[j] = (out < 0 && f + j < a.F) ? rg_epilogue(a, s[j], row, f + j, scale, dr) : s[j];
+      rg_store<V>(a, dst, o, f, aligned_for);
+    };
 #pragma unroll
-        for (int v = 0; v < V; ++v)
-          o[v] = out < 0 ? rg_epilogue(a, acc[r][c][v], row, f + v, scale, dr) : acc[r][c][v];
-        store_vec<V>(dst + f, o, aligned_for);
-      }
+    for (int c = 0; c < C4; ++c) put(std::integral_constant<int, 4>{}, c * 256 + lane * 4, &acc[r][4 * c]);
+#pragma unroll
+    for (int c = 0; c < C2; ++c)
+      put(std::integral_constant<int, 2>{}, L::kOff2 + c * 128 + lane * 2, &acc[r][4 * C4 + 2 * c]);
+#pragma unroll
+    for (int c = 0; c < C1; ++c)
+      put(std::integral_constant<int, 1>{}, L::kOff1 + c * 64 + lane, &acc[r][4 * C4 + 2 * C2 + c]);
+  }
+}
+
+// One wavefront per work item; a lane owns NF features of all R accumulated rows.
+// Merged columns are taken 64 at a time through a VGPR (ids and masks) and handed to
+// the scalar unit by v_readlane; every row of a group is summed in ascending column
+// order.
+template <int R, int C4, int C2, int C1, int U, bool BIGX>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
+  using L = Lay<C4, C2, C1>;
+  constexpr int NF = L::NF;
+  const int lane = threadIdx.x & (kWave - 1);
+  // Launch slots are laid out so that the workgroups of one XCD walk one contiguous,
+  // work-balanced stretch of the column-ordered item list (k_item_deal).
+  const int item = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * kWavesPerBlock + int(threadIdx.x) / kWave);
+  if (item >= a.items) return;
+  const int out = a.item_out[item];
+  if (out < -1) return;   // padding slot
+  const int g = a.item_group[item];
+  const int m0 = a.item_m0[item], m1 = a.item_m1[item];
+  const i32x4 rsrc = make_rsrc(a.X, BIGX ? 0u : uint32_t(a.x_bytes));
+  float acc[R][NF];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[r][i] = 0.0f;
+
+  int32_t ncols = 0;
+  uint32_t nmask = 0;
+  if (m0 + lane < m1) {
+    ncols = a.gcol[m0 + lane];
+    nmask = a.gmask[m0 + lane];
+  }
+  // Two fetch buffers: while the rows of one step are added, the fetches of the
+  // following step are already in flight (also across the 64-column batches).
+  // Invariant at the top of a batch: xa holds the batch's step 0 iff the batch has
+  // at least U columns.  Every batch but an item's last is full and 64 / U is even,
+  // so an odd number of full steps can only occur in the last batch.
+  float xa[U][NF], xb[U][NF];
+  if (min(kWave, m1 - m0) >= U) rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, ncols, 0, lane, xa);
+  for (int m = m0; m < m1; m += kWave) {
+    const int32_t cols = ncols;
+    const uint32_t masks = nmask;
+    const int cnt = min(kWave, m1 - m);
+    const bool more = m + kWave < m1;
+    const bool mine = m + kWave + lane < m1;
+    if (more) {
+      ncols = mine ? a.gcol[m + kWave + lane] : 0;
+      nmask = mine ? a.gmask[m + kWave + lane] : 0u;
+    }
+    const int nfull = cnt / U * U;
+    const bool next_full_step = more && (m1 - (m + kWave)) >= U;
+    int k = 0;
+    for (; k + 2 * U <= nfull; k += 2 * U) {
+      rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, cols, k + U, lane, xb);
+      rg_accum<R, NF, U>(masks, k, xa, acc);
+      if (k + 2 * U < nfull) rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, cols, k + 2 * U, lane, xa);
+      else if (next_full_step) rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, ncols, 0, lane, xa);
+      rg_accum<R, NF, U>(masks, k + U, xb, acc);
+    }
+    if (k < nfull) {   // odd count of full steps: last batch only, xa holds the step
+      rg_accum<R, NF, U>(masks, k, xa, acc);
+      k += U;
+    }
+    for (; k < cnt; ++k) {
+      float x1[1][NF];
+      rg_load<L, C4, C2, C1, 1, BIGX>(a, rsrc, cols, k, lane, x1);
+      rg_accum<R, NF, 1>(masks, k, x1, acc);
     }
   }
+  rg_write_rows<R, C4, C2, C1>(a, acc, g, out, lane);
 }
 
 // rows of a group cut into several items: add the items' partial rows in order
@@ -573,19 +625,14 @@ __global__ void k_rg_combine(RgArgs a) {
   }
 }
 
-template <int R, int V, int C>
-int launch_rg(const RgArgs& a, bool hasd, hipStream_t st) {
-  // row fetches in flight per wavefront: about 8 vector loads
-  constexpr int U = C == 1 ? 8 : (C == 2 ? 4 : 2);
+template <int R, int C4, int C2, int C1>
+int launch_rg(const RgArgs& a, hipStream_t st) {
+  // row fetches in flight per wavefront and buffer: about 8-10 registers' worth of loads
+  constexpr int NF = Lay<C4, C2, C1>::NF;
+  constexpr int U = NF <= 2 ? 8 : (NF <= 4 ? 4 : 2);
   const dim3 grid(unsigned((a.items + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWave * kWavesPerBlock);
-  const bool bigx = a.x_bytes >= (int64_t(1) << 32);
-  if (hasd) {
-    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, true, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, true, false>), grid, block, 0, st, a);
-  } else {
-    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_rg_spmm<R, V, C, U, false, false>), grid, block, 0, st, a);
-  }
+  if (a.x_bytes >= (int64_t(1) << 32)) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, false>), grid, block, 0, st, a);
   HIP_TRY(hipGetLastError());
   if (a.n_long > 0) {
     hipLaunchKernelGGL(k_rg_combine<R>, dim3(unsigned(a.n_long), R), dim3(256), 0, st, a);
@@ -594,40 +641,60 @@ int launch_rg(const RgArgs& a, bool hasd, hipStream_t st) {
   return SGNN_OK;
 }
 
-// (V, C) from F as sgnn_rowgroup_config reports it; R is the plan's
-template <int V>
-int dispatch_rg_c(const RgArgs& a, int R, int C, bool hasd, hipStream_t st) {
-  if (R == 16) {
-    if constexpr (V <= 2) {
-      if (C == 1) return launch_rg<16, V, 1>(a, hasd, st);
-      if (C == 2) return launch_rg<16, V, 2>(a, hasd, st);
-      if (C == 3) return launch_rg<16, V, 3>(a, hasd, st);
-      if (C == 4) return launch_rg<16, V, 4>(a, hasd, st);
-      if (C == 5) return launch_rg<16, V, 5>(a, hasd, st);
-    } else {
-      if (C == 1) return launch_rg<16, V, 1>(a, hasd, st);
-      if (C == 2) return launch_rg<16, V, 2>(a, hasd, st);
-    }
-  } else if (R == 8) {
-    if (C == 1) return launch_rg<8, V, 1>(a, hasd, st);
-    if (C == 2) return launch_rg<8, V, 2>(a, hasd, st);
-    if (C == 3) return launch_rg<8, V, 3>(a, hasd, st);
-    if (C == 4) return launch_rg<8, V, 4>(a, hasd, st);
-    if (C == 5) return launch_rg<8, V, 5>(a, hasd, st);
+// Feature layout for width F: as many 16-byte chunks as fit, the remainder in one
+// narrower chunk (or one more 16-byte chunk when it is longer than an 8-byte chunk holds).
+struct Layout {
+  int c4, c2, c1;
+  int nf() const { return 4 * c4 + 2 * c2 + c1; }
+};
+
+Layout rg_layout(int64_t F) {
+  Layout l{int(F / 256), 0, 0};
+  const int64_t rem = F - int64_t(l.c4) * 256;
+  if (rem > 128) l.c4 += 1;
+  else if (rem > 64) l.c2 = 1;
+  else if (rem > 0) l.c1 = 1;
+  return l;
+}
+
+// rows per group for a layout: the accumulators (R * NF registers per lane) must leave
+// room for two wavefronts per SIMD; narrow rows are bound by the mask tests, not the
+// gather, and keep R = 8
+int rg_rows_for(int64_t F) {
+  if (F < 33) return 0;
+  const Layout l = rg_layout(F);
+  if (g_R_override == 8 && l.nf() <= 20) return 8;
+  if (g_R_override == 16 && l.nf() <= 10) return 16;
+  if (l.nf() <= 10 && F > 128) return 16;
+  return l.nf() <= 20 ? 8 : 0;
+}
+
+template <int R, int C4>
+int dispatch_rg_tail(const RgArgs& a, const Layout& l, hipStream_t st) {
+  if (l.c2 == 0 && l.c1 == 0) {
+    if constexpr (C4 > 0) return launch_rg<R, C4, 0, 0>(a, st);
+  } else if (l.c2 == 1 && l.c1 == 0) {
+    if constexpr (4 * C4 + 2 <= (R == 16 ? 10 : 20)) return launch_rg<R, C4, 1, 0>(a, st);
+  } else if (l.c2 == 0 && l.c1 == 1) {
+    if constexpr (4 * C4 + 1 <= (R == 16 ? 10 : 20)) return launch_rg<R, C4, 0, 1>(a, st);
   }
   return fail(SGNN_ERR_UNSUPPORTED, "no row-group kernel for this (R, F)");
 }
 
-// widest vector that divides F and still keeps more than half the lanes busy
-bool rg_layout(int64_t F, int* V, int* C) {
-  int v = 1;
-  if (F % 4 == 0 && F / 4 > 32) v = 4;
-  else if (F % 2 == 0 && F / 2 > 32) v = 2;
-  const int64_t c = (F + int64_t(kWave) * v - 1) / (int64_t(kWave) * v);
-  if (c > 5) return false;
-  *V = v;
-  *C = int(c);
-  return true;
+int dispatch_rg(const RgArgs& a, int R, const Layout& l, hipStream_t st) {
+  if (R == 16 && l.nf() <= 10) {
+    if (l.c4 == 0) return dispatch_rg_tail<16, 0>(a, l, st);
+    if (l.c4 == 1) return dispatch_rg_tail<16, 1>(a, l, st);
+    if (l.c4 == 2) return dispatch_rg_tail<16, 2>(a, l, st);
+  } else if (R == 8 && l.nf() <= 20) {
+    if (l.c4 == 0) return dispatch_rg_tail<8, 0>(a, l, st);
+    if (l.c4 == 1) return dispatch_rg_tail<8, 1>(a, l, st);
+    if (l.c4 == 2) return dispatch_rg_tail<8, 2>(a, l, st);
+    if (l.c4 == 3) return dispatch_rg_tail<8, 3>(a, l, st);
+    if (l.c4 == 4) return dispatch_rg_tail<8, 4>(a, l, st);
+    if (l.c4 == 5) return dispatch_rg_tail<8, 5>(a, l, st);
+  }
+  return fail(SGNN_ERR_UNSUPPORTED, "no row-group kernel for this (R, F)");
 }
 
 }  // namespace
@@ -640,12 +707,7 @@ void set_rowgroup_order(int cols) { g_order_cols = cols > 0 ? cols : 4096; }
 
 extern "C" {
 
-int sgnn_rowgroup_config(int64_t F) {
-  int V, C;
-  if (F < 33 || !rg_layout(F, &V, &C)) return 0;
-  if (g_R_override == 8 || (g_R_override == 16 && V * C <= 10)) return g_R_override;
-  return (V * C <= 10) ? (F <= 128 ? 8 : 16) : 8;
-}
+int sgnn_rowgroup_config(int64_t F) { return rg_rows_for(F); }
 
 size_t sgnn_rowgroup_plan_bytes(int64_t n_rows, int64_t nnz, int R) {
   if (n_rows <= 0 || nnz < 0 || (R != 8 && R != 16)) return 0;
@@ -752,8 +814,12 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
     return fail(SGNN_ERR_INVALID, "X and Y must be 4-byte aligned");
   if (epilogue != SGNN_EPI_SCALE_ROW && epilogue != SGNN_EPI_SCALE_ROW2)
     return fail(SGNN_ERR_INVALID, "unknown epilogue mode");
-  int V, C;
-  if (!rg_layout(F, &V, &C)) return fail(SGNN_ERR_UNSUPPORTED, "F too wide for the row-group kernel");
+  if (dinv_col != nullptr)
+    return fail(SGNN_ERR_UNSUPPORTED, "the row-group kernel takes X already scaled by columns (sgnn_row_scale_f32)");
+  if (reinterpret_cast<uintptr_t>(X) % 16 || ldx % 4)
+    return fail(SGNN_ERR_UNSUPPORTED, "the row-group kernel needs X 16-byte aligned with ldx a multiple of 4");
+  if (F < 33) return fail(SGNN_ERR_UNSUPPORTED, "F too narrow for the row-group kernel");
+  const Layout lay = rg_layout(F);
   Plan p = carve_plan(const_cast<void*>(plan), n_rows, nnz, R);
   if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "row-group plan buffer too small");
   if (items <= 0 || items > p.cap_slots || slots < 0 || n_long < 0 || n_long > p.cap_long)
@@ -764,7 +830,7 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   a.grows = p.grows; a.gptr = p.gptr; a.gcol = p.gcol; a.gmask = p.gmask;
   a.item_group = p.item_group; a.item_m0 = p.item_m0; a.item_m1 = p.item_m1; a.item_out = p.item_out;
   a.long_group = p.long_group; a.long_slot = p.long_slot;
-  a.dinv_row = dinv_row; a.dinv_col = dinv_col; a.X = X; a.Y = Y; a.partial = static_cast<float*>(workspace);
+  a.dinv_row = dinv_row; a.X = X; a.Y = Y; a.partial = static_cast<float*>(workspace);
   a.w_off = w_off; a.corr = corr; a.x_row_offset = x_row_offset;
   if (corr && (x_row_offset < 0 || x_row_offset + n_rows > n_cols))
     return fail(SGNN_ERR_INVALID, "x_row_offset places the block's own rows outside X");
@@ -776,10 +842,7 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   a.epilogue = epilogue;
   a.seg = seg_cols_for(nnz);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool hasd = dinv_col != nullptr;
-  if (V == 4) return dispatch_rg_c<4>(a, R, C, hasd, st);
-  if (V == 2) return dispatch_rg_c<2>(a, R, C, hasd, st);
-  return dispatch_rg_c<1>(a, R, C, hasd, st);
+  return dispatch_rg(a, R, lay, st);
 }
 
 }  // extern "C"

@@ -150,7 +150,8 @@ class PartitionedAdj:
         b = self._gather.get(key)
         if b is None:
             rows = self.max_rows * self.world
-            b = [torch.zeros((rows, F), dtype=dtype, device=device) for _ in range(2)]
+            Fp = (F + 3) // 4 * 4      # rows on 16-byte boundaries for the row-group kernel's loads
+            b = [torch.zeros((rows, Fp), dtype=dtype, device=device) for _ in range(2)]
             self._gather = {key: b}
         return b
 
@@ -185,19 +186,19 @@ class PartitionedAdj:
         src = X_local
         out = None
         for h in range(order):
-            full = bufs[h % 2]
+            full = bufs[h % 2]                       # [padded rows, F rounded up to 4]; whole rows travel
             piece = full[lo:lo + self.max_rows]
             if h == 0:
-                self.local.scale_rows_into(src, piece[:rows])           # utils.py:93
+                self.local.scale_rows_into(src, piece[:rows, :F])       # utils.py:93
             # later hops: the previous epilogue already wrote the doubly scaled rows into `piece`
             self._all_gather(full, piece)
             last = h == order - 1
             if last:
                 out = torch.empty((rows, F), dtype=X_local.dtype, device=X_local.device)
-                self.local.spmm_into(full, out, final=True)
+                self.local.spmm_into(full[:, :F], out, final=True)
             else:
-                nxt = bufs[(h + 1) % 2][lo:lo + rows]
-                self.local.spmm_into(full, nxt, final=False)            # epilogue: (s*d)*d
+                nxt = bufs[(h + 1) % 2][lo:lo + rows, :F]
+                self.local.spmm_into(full[:, :F], nxt, final=False)     # epilogue: (s*d)*d
         return out
 
     def _propagate_sliced(self, X_local, order, slices):
@@ -220,14 +221,13 @@ class PartitionedAdj:
             fulls, events = [], []
             for s in range(len(bounds) - 1):
                 f0, f1 = bounds[s], bounds[s + 1]
-                full = torch.empty((self.max_rows * self.world, f1 - f0), dtype=X_local.dtype, device=dev)
+                w = f1 - f0
+                full = torch.zeros((self.max_rows * self.world, (w + 3) // 4 * 4), dtype=X_local.dtype, device=dev)
                 piece = full[lo:lo + self.max_rows]
-                if rows < self.max_rows:
-                    piece[rows:].zero_()
                 if h == 0:
-                    self.local.scale_rows_into(cur[:, f0:f1], piece[:rows])
+                    self.local.scale_rows_into(cur[:, f0:f1], piece[:rows, :w])
                 else:
-                    piece[:rows].copy_(cur[:, f0:f1])                   # already doubly scaled
+                    piece[:rows, :w].copy_(cur[:, f0:f1])               # already doubly scaled
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(comm):
@@ -241,7 +241,7 @@ class PartitionedAdj:
             for s in range(len(bounds) - 1):
                 f0, f1 = bounds[s], bounds[s + 1]
                 main.wait_event(events[s])
-                self.local.spmm_into(fulls[s], out[:, f0:f1], final=last)
+                self.local.spmm_into(fulls[s][:, :f1 - f0], out[:, f0:f1], final=last)
             cur = out
         return cur
 
@@ -313,7 +313,8 @@ class _LocalBlock:
         F = full.shape[1]
         dev = full.device
         epi = _lib.EPI_SCALE_ROW if final else _lib.EPI_SCALE_ROW2
-        plan = self._plan(F)
+        aligned = full.data_ptr() % 16 == 0 and full.stride(0) % 4 == 0      # 16-byte row loads
+        plan = self._plan(F) if aligned else None
         if plan is not None:
             nbytes = lib.sgnn_spmm_rowgroup_workspace_bytes(plan["slots"], plan["R"], F)
             ws = self._ws.get(("rg", F))

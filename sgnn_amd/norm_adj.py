@@ -227,13 +227,15 @@ class NormAdj:
         exists for this width, the plain CSR kernel otherwise."""
         lib = _lib.load()
         dinv = _lib.ptr(self.dinv)
-        plan = self._rowgroup_plan(F)
+        # the row-group kernel reads rows of X with 16-byte loads and takes X already scaled
+        aligned = X.data_ptr() % 16 == 0 and ldx % 4 == 0
+        plan = self._rowgroup_plan(F) if (aligned and not scale_cols) else None
         if plan is not None:
             ws = self._rowgroup_ws(plan, F)
             _lib.check(lib.sgnn_spmm_rowgroup_f32(
                 self.n, self.n, self.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
                 plan["items"], plan["slots"], plan["n_long"],
-                dinv if scale_rows else None, dinv if scale_cols else None,
+                dinv if scale_rows else None, None,
                 float(self.w_off), _lib.ptr(self.corr), 0,
                 _lib.ptr(X), ldx, _lib.ptr(Y), ldy, int(epilogue), _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(self.device)))
@@ -268,9 +270,25 @@ class NormAdj:
             Y = torch.empty((self.n, F), dtype=torch.float32, device=self.device) if out is None else out
             if F == 0:
                 return Y
-            self._hop(X, X.stride(0) if X.shape[0] > 1 else F, Y, Y.stride(0) if self.n > 1 else F, F,
-                      scale_rows, scale_cols, epilogue)
+            ldx = X.stride(0) if X.shape[0] > 1 else F
+            if self._rowgroup_plan(F) is not None and (scale_cols or X.data_ptr() % 16 or ldx % 4):
+                # stage X for the row-group kernel: column scaling applied (utils.py:93),
+                # rows on 16-byte boundaries
+                X = self._staged(X, ldx, F, scale_cols)
+                ldx, scale_cols = X.stride(0), False
+            self._hop(X, ldx, Y, Y.stride(0) if self.n > 1 else F, F, scale_rows, scale_cols, epilogue)
         return Y
+
+    def _staged(self, X, ldx, F, scale):
+        """Copy of X (times dinv per row if ``scale``) whose rows start on 16-byte boundaries."""
+        Fp = (F + 3) // 4 * 4
+        Xs = torch.empty((self.n, Fp), dtype=torch.float32, device=self.device)
+        if scale:
+            _lib.check(_lib.load().sgnn_row_scale_f32(self.n, F, _lib.ptr(self.dinv), _lib.ptr(X), ldx,
+                                                      _lib.ptr(Xs), Fp, _lib.current_stream(self.device)))
+        else:
+            Xs[:, :F].copy_(X)
+        return Xs
 
     def propagate(self, X, order=1):
         """``A_hat^order . X`` — the whole loop of utils.py:91-96 in ``order`` SpMM
@@ -300,23 +318,19 @@ class NormAdj:
             # Row-group kernel: scale X by dinv once up front (utils.py:93) instead of
             # gathering dinv[col] per fetched row inside the kernel — measured 6 % faster
             # on the Reddit shape, the extra pass over X included.
-            lib = _lib.load()
-            Xs = torch.empty((self.n, F), dtype=torch.float32, device=self.device)
-            _lib.check(lib.sgnn_row_scale_f32(self.n, F, _lib.ptr(self.dinv), _lib.ptr(X),
-                                              X.stride(0) if X.shape[0] > 1 else F, _lib.ptr(Xs), F,
-                                              _lib.current_stream(self.device)))
-            # ping-pong so that the last hop lands in Y and no hop reads what it writes
-            if order % 2 == 1:
-                ring = [Y, Xs]
-            else:
-                ring = [torch.empty((self.n, F), dtype=torch.float32, device=self.device), Y]
-            src = Xs
+            # The kernel reads rows with 16-byte loads, so the scaled copy and the
+            # intermediates of a chain live in buffers whose row stride is a multiple of
+            # 4 floats; only the last hop writes the caller-visible Y.
+            src = self._staged(X, X.stride(0) if X.shape[0] > 1 else F, F, True)
+            Fp = src.stride(0)
+            spare = torch.empty((self.n, Fp), dtype=torch.float32, device=self.device) if order > 1 else None
             for h in range(order):
                 last = h == order - 1
-                dst = ring[h % 2]
-                self._hop(src, F, dst, F, F, True, False,
+                dst, ldd = (Y, F) if last else (spare, Fp)
+                self._hop(src, Fp, dst, ldd, F, True, False,
                           _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2)
-                src = dst
+                if not last:
+                    src, spare = dst, src         # ping-pong: no hop reads what it writes
         return Y
 
     # --------------------------------------------------------------- sampling
