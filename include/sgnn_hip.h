@@ -181,13 +181,18 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                        to the 8 XCDs in contiguous, work-balanced runs padded to
  *                        equal length, so the count can exceed the item count.
  * sgnn_spmm_rowgroup_f32 workspace >= sgnn_spmm_rowgroup_workspace_bytes(slots, R, F).
+ *                        X must already carry the column scaling of utils.py:93
+ *                        (sgnn_row_scale_f32; dinv_col must be NULL) and its rows must
+ *                        start on 16-byte boundaries (X 16-byte aligned, ldx % 4 == 0):
+ *                        the kernel reads them with 16-byte loads; SGNN_ERR_UNSUPPORTED
+ *                        otherwise, and for F < 33 or F > 1280.
  *                        The plan stores the sparsity pattern only.  An adjacency whose
  *                        off-diagonal entries all carry one weight w_off (Reddit's A + A^T
  *                        has 2.0, data_loader.py:75) is handled in the epilogue:
  *                        row i = w_off * (pattern sum) + corr[i] * x'_i with
  *                        corr[i] = (diagonal value of row i) - w_off where the row stores
- *                        a diagonal entry, else 0; x'_i is row (i + x_row_offset) of X
- *                        (times dinv_col).  Unit weights: w_off = 1, corr = NULL.
+ *                        a diagonal entry, else 0; x'_i is row (i + x_row_offset) of X.
+ *                        Unit weights: w_off = 1, corr = NULL.
  * No reference counterpart for the plan itself: the reference keeps only the
  * COO tensor (utils.py:54-62).
  */
