@@ -121,6 +121,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     n, E, F = SHAPES[args.workload]
+    if rank == 0:
+        print(f"[bench] {args.workload}: drawing the graph on {world} rank(s)", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     row, col = rmat_undirected_device(n, E, seed=args.seed, device=device, max_degree=args.max_degree)
     torch.cuda.synchronize()
@@ -196,6 +198,9 @@ def main():
             step_fn, info = build_grid(fg)
             t = probe(step_fn) if len(candidates) > 1 else 0.0
             probed[str(fg)] = round(t * 1e3, 3)
+            if rank == 0:
+                print(f"[bench] grid {fg} feature slices x {world // fg} row blocks: built in "
+                      f"{info['adjacency_build_ms']:.0f} ms, probe {t * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
             if best is None or t < best[0]:
                 best = (t, step_fn, info)
             else:
