@@ -185,7 +185,8 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                        (sgnn_row_scale_f32; dinv_col must be NULL) and its rows must
  *                        start on 16-byte boundaries (X 16-byte aligned, ldx % 4 == 0):
  *                        the kernel reads them with 16-byte loads; SGNN_ERR_UNSUPPORTED
- *                        otherwise, and for F < 33 or F > 1280.
+ *                        otherwise, and for F < 33.  Widths above 640 run as equal
+ *                        feature slices of at most 640 columns, one launch each.
  *                        The plan stores the sparsity pattern only.  An adjacency whose
  *                        off-diagonal entries all carry one weight w_off (Reddit's A + A^T
  *                        has 2.0, data_loader.py:75) is handled in the epilogue:

@@ -657,16 +657,27 @@ Layout rg_layout(int64_t F) {
   return l;
 }
 
+// Widths beyond what 16 rows x 10 registers hold are cut into equal feature slices of at
+// most 640 columns, one launch per slice (measured on the Reddit shape: F = 1024 as one
+// R = 8 launch 26.7 ms, as two R = 16 slices 15.8 ms).
+constexpr int64_t kMaxSlice = 640;
+
+int64_t rg_slice_width(int64_t F) {
+  if (F <= kMaxSlice) return F;
+  const int64_t ns = (F + kMaxSlice - 1) / kMaxSlice;
+  return ((F + ns - 1) / ns + 3) / 4 * 4;
+}
+
 // rows per group for a layout: the accumulators (R * NF registers per lane) must leave
 // room for two wavefronts per SIMD; narrow rows are bound by the mask tests, not the
 // gather, and keep R = 8
 int rg_rows_for(int64_t F) {
   if (F < 33) return 0;
+  F = rg_slice_width(F);
   const Layout l = rg_layout(F);
-  if (g_R_override == 8 && l.nf() <= 20) return 8;
-  if (g_R_override == 16 && l.nf() <= 10) return 16;
-  if (l.nf() <= 10 && F > 128) return 16;
-  return l.nf() <= 20 ? 8 : 0;
+  if (l.nf() > 10) return 0;   // cannot happen for a slice of at most 640 columns
+  if (g_R_override == 8 || g_R_override == 16) return g_R_override;
+  return F > 128 ? 16 : 8;
 }
 
 template <int R, int C4>
@@ -674,9 +685,9 @@ int dispatch_rg_tail(const RgArgs& a, const Layout& l, hipStream_t st) {
   if (l.c2 == 0 && l.c1 == 0) {
     if constexpr (C4 > 0) return launch_rg<R, C4, 0, 0>(a, st);
   } else if (l.c2 == 1 && l.c1 == 0) {
-    if constexpr (4 * C4 + 2 <= (R == 16 ? 10 : 20)) return launch_rg<R, C4, 1, 0>(a, st);
+    if constexpr (4 * C4 + 2 <= 10) return launch_rg<R, C4, 1, 0>(a, st);
   } else if (l.c2 == 0 && l.c1 == 1) {
-    if constexpr (4 * C4 + 1 <= (R == 16 ? 10 : 20)) return launch_rg<R, C4, 0, 1>(a, st);
+    if constexpr (4 * C4 + 1 <= 10) return launch_rg<R, C4, 0, 1>(a, st);
   }
   return fail(SGNN_ERR_UNSUPPORTED, "no row-group kernel for this (R, F)");
 }
@@ -686,13 +697,10 @@ int dispatch_rg(const RgArgs& a, int R, const Layout& l, hipStream_t st) {
     if (l.c4 == 0) return dispatch_rg_tail<16, 0>(a, l, st);
     if (l.c4 == 1) return dispatch_rg_tail<16, 1>(a, l, st);
     if (l.c4 == 2) return dispatch_rg_tail<16, 2>(a, l, st);
-  } else if (R == 8 && l.nf() <= 20) {
+  } else if (R == 8 && l.nf() <= 10) {
     if (l.c4 == 0) return dispatch_rg_tail<8, 0>(a, l, st);
     if (l.c4 == 1) return dispatch_rg_tail<8, 1>(a, l, st);
     if (l.c4 == 2) return dispatch_rg_tail<8, 2>(a, l, st);
-    if (l.c4 == 3) return dispatch_rg_tail<8, 3>(a, l, st);
-    if (l.c4 == 4) return dispatch_rg_tail<8, 4>(a, l, st);
-    if (l.c4 == 5) return dispatch_rg_tail<8, 5>(a, l, st);
   }
   return fail(SGNN_ERR_UNSUPPORTED, "no row-group kernel for this (R, F)");
 }
@@ -819,7 +827,6 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   if (reinterpret_cast<uintptr_t>(X) % 16 || ldx % 4)
     return fail(SGNN_ERR_UNSUPPORTED, "the row-group kernel needs X 16-byte aligned with ldx a multiple of 4");
   if (F < 33) return fail(SGNN_ERR_UNSUPPORTED, "F too narrow for the row-group kernel");
-  const Layout lay = rg_layout(F);
   Plan p = carve_plan(const_cast<void*>(plan), n_rows, nnz, R);
   if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "row-group plan buffer too small");
   if (items <= 0 || items > p.cap_slots || slots < 0 || n_long < 0 || n_long > p.cap_long)
@@ -830,19 +837,32 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   a.grows = p.grows; a.gptr = p.gptr; a.gcol = p.gcol; a.gmask = p.gmask;
   a.item_group = p.item_group; a.item_m0 = p.item_m0; a.item_m1 = p.item_m1; a.item_out = p.item_out;
   a.long_group = p.long_group; a.long_slot = p.long_slot;
-  a.dinv_row = dinv_row; a.X = X; a.Y = Y; a.partial = static_cast<float*>(workspace);
+  a.dinv_row = dinv_row; a.partial = static_cast<float*>(workspace);
   a.w_off = w_off; a.corr = corr; a.x_row_offset = x_row_offset;
   if (corr && (x_row_offset < 0 || x_row_offset + n_rows > n_cols))
     return fail(SGNN_ERR_INVALID, "x_row_offset places the block's own rows outside X");
-  a.ldx = ldx; a.ldy = ldy; a.x_bytes = ((n_cols - 1) * ldx + F) * 4;
-  a.items = int32_t(items); a.n_long = int32_t(n_long); a.F = int32_t(F);
-  a.row_bytes = a.x_bytes < (int64_t(1) << 32) ? int32_t(ldx * 4) : 0;
-  const uintptr_t py = reinterpret_cast<uintptr_t>(Y);
-  a.y_vec = (py % 16 == 0 && ldy % 4 == 0) ? 4 : ((py % 8 == 0 && ldy % 2 == 0) ? 2 : 1);
+  a.ldx = ldx; a.ldy = ldy;
+  a.items = int32_t(items); a.n_long = int32_t(n_long);
   a.epilogue = epilogue;
   a.seg = seg_cols_for(nnz);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return dispatch_rg(a, R, lay, st);
+  // one launch per feature slice (a single one up to 640 columns); the slices share the
+  // partial-row workspace, which is safe because they run in order on one stream
+  const int64_t width = rg_slice_width(F);
+  for (int64_t f0 = 0; f0 < F; f0 += width) {
+    const int64_t w = F - f0 < width ? F - f0 : width;
+    if (w < 33) return fail(SGNN_ERR_UNSUPPORTED, "feature slice too narrow for the row-group kernel");
+    a.X = X + f0;
+    a.Y = Y + f0;
+    a.F = int32_t(w);
+    a.x_bytes = ((n_cols - 1) * ldx + w) * 4;
+    a.row_bytes = a.x_bytes < (int64_t(1) << 32) ? int32_t(ldx * 4) : 0;
+    const uintptr_t py = reinterpret_cast<uintptr_t>(a.Y);
+    a.y_vec = (py % 16 == 0 && ldy % 4 == 0) ? 4 : ((py % 8 == 0 && ldy % 2 == 0) ? 2 : 1);
+    const int rc = dispatch_rg(a, R, rg_layout(w), st);
+    if (rc != SGNN_OK) return rc;
+  }
+  return SGNN_OK;
 }
 
 }  // extern "C"
