@@ -152,7 +152,7 @@ def main():
             padj = PartitionedAdj.from_coo(row, col, None, n, device, row_rank, row_world, group=group)
             torch.cuda.synchronize()
             build_ms = (time.perf_counter() - t0) * 1e3
-            Xl = X[padj.row_begin:padj.row_end, f0:f1].contiguous()
+            Xl = X[padj.rows.to(device)][:, f0:f1].contiguous()
             # the overlapped (feature-sliced) exchange is used only if it reproduces the
             # plain one on this machine; every rank of the job takes the same decision
             slices = max(1, args.slices) if row_world > 1 else 1

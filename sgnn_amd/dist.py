@@ -3,9 +3,15 @@
 The reference's own multi-GPU mode is replication: every rank loads the whole
 graph and recomputes the whole ``A_hat . X`` (main.py:39-41, model/SGNN.py:518-520
 — the DDP wrapper is bypassed through ``.module.run``), so there is nothing to be
-compatible with beyond the result.  Here the rows of ``A_hat`` are split into
-``world`` contiguous blocks of about equal stored entries; rank p owns block p of
-the matrix, of ``dinv`` and of X / Y.  One hop is
+compatible with beyond the result.  Here the rows of ``A_hat`` are dealt out to the
+``world`` ranks; rank p owns its rows of the matrix, of ``dinv`` and of X / Y
+(``PartitionedAdj.rows`` lists them).  The default deal is cyclic over the rows in
+degree order (row of degree rank k goes to rank k mod world): every rank gets the
+same number of rows and, to within one row's worth, the same number of stored
+entries, so the exchange carries no padding and the SpMMs finish together.  (A
+contiguous split balanced by stored entries is kept as ``partition="contiguous"``;
+on the Reddit-shape graph its blocks hold 3 107 ... 76 195 rows at 8 ranks and the
+equal-piece all-gather moves 2.6 times the rows there are.)  One hop is
 
   1. scale the local rows of X by the local ``dinv``          (utils.py:93)
   2. all-gather the scaled blocks into one padded buffer      (RCCL over xGMI)
@@ -13,8 +19,9 @@ the matrix, of ``dinv`` and of X / Y.  One hop is
   4. scale the local output rows by the local ``dinv``        (utils.py:95, fused)
 
 Blocks are padded to a common row count so that the exchange is ONE
-``all_gather_into_tensor`` of equal pieces; the local CSR's column ids are
-remapped once into the padded index space.  Pre-scaling before the exchange means
+``all_gather_into_tensor`` of equal pieces; node ids are remapped once into the
+padded index space (owner * max_rows + position in the owner's block), in which
+every rank's rows are contiguous.  Pre-scaling before the exchange means
 ``dinv`` itself never travels.  With ``slices > 1`` the feature dimension is cut
 into column slices and the all-gather of slice s+1 runs on a side stream while
 slice s is multiplied, which hides most of the exchange behind the SpMM.
@@ -97,7 +104,7 @@ def balanced_row_splits(counts, world):
 
 def pad_index_map(splits):
     """Column id -> position in the padded gather buffer (block p starts at
-    p * max_rows)."""
+    p * max_rows), for a contiguous split."""
     world = len(splits) - 1
     max_rows = max(splits[p + 1] - splits[p] for p in range(world))
     n = splits[-1]
@@ -107,14 +114,30 @@ def pad_index_map(splits):
     return m, max_rows
 
 
-class PartitionedAdj:
-    """Rank-local row block of ``A + I`` plus what one hop needs."""
+def degree_cyclic_deal(counts, world):
+    """Deal the rows out cyclically in order of decreasing ``counts`` (stable): the row of
+    degree rank k goes to rank ``k % world``, position ``k // world``.  Returns
+    ``(order, max_rows)`` with ``order`` the rows by degree rank (int64 tensor on the
+    CPU); deterministic, so every rank computes the same deal."""
+    c = torch.as_tensor(counts).to(torch.int64).cpu()
+    order = torch.argsort(c, descending=True, stable=True)
+    return order, (c.numel() + world - 1) // world
 
-    def __init__(self, local, splits, rank, world, n, global_nnz, global_max_degree, group=None):
-        self.local = local                      # NormAdj-like over (rows_local x padded columns)
-        self.splits, self.rank, self.world, self.n = splits, rank, world, n
-        self.row_begin, self.row_end = splits[rank], splits[rank + 1]
-        self.max_rows = max(splits[p + 1] - splits[p] for p in range(world))
+
+class PartitionedAdj:
+    """Rank-local rows of ``A + I`` plus what one hop needs.  ``rows`` (int64 tensor,
+    CPU) lists the global rows this rank owns, in the order of its local block: the
+    caller hands ``X[rows]`` to ``propagate`` and gets ``Y[rows]`` back."""
+
+    def __init__(self, local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group=None,
+                 splits=None):
+        self.local = local                      # block over (rows_local x padded columns)
+        self.rows, self.rank, self.world, self.n = rows, rank, world, n
+        self.n_local = int(rows.numel())
+        self.max_rows = int(max_rows)
+        self.splits = splits                    # contiguous partition only
+        self.row_begin = splits[rank] if splits is not None else None
+        self.row_end = splits[rank + 1] if splits is not None else None
         self.global_nnz, self.global_max_degree = global_nnz, global_max_degree
         self.group = group
         self._gather = {}
@@ -122,27 +145,45 @@ class PartitionedAdj:
 
     # ------------------------------------------------------------------ build
     @classmethod
-    def from_coo(cls, row, col, val, n, device, rank, world, group=None, local_factory=None):
-        """Every rank passes the same COO (entries of other ranks' rows are
-        dropped here).  ``local_factory`` is a test hook that builds the local
-        block object from ``(row_local, col_padded, val, n_rows, n_cols, dinv_seed)``;
-        the default builds the device CSR through the C ABI."""
+    def from_coo(cls, row, col, val, n, device, rank, world, group=None, local_factory=None,
+                 partition="degree_cyclic"):
+        """Every rank passes the same COO (entries of other ranks' rows are dropped
+        here).  ``local_factory`` is a test hook that builds the local block from
+        ``(row_padded, col_padded, val, n_rows, n_padded, first_padded_row)``; the
+        default builds the device CSR through the C ABI."""
         row = torch.as_tensor(row).to(torch.int64)
         col = torch.as_tensor(col).to(torch.int64)
         counts = torch.bincount(row, minlength=n) + 1            # + the self-loop every row gets
-        splits = balanced_row_splits(counts, world)
-        r0, r1 = splits[rank], splits[rank + 1]
-        mine = (row >= r0) & (row < r1)
-        lrow, lcol = row[mine], col[mine]
-        lval = None if val is None else torch.as_tensor(val)[mine]
         global_nnz = int(counts.sum().item())
         global_max_degree = int(counts.max().item())
-        padmap, max_rows = pad_index_map(splits)
-        if local_factory is not None:
-            local = local_factory(lrow - r0, lcol, lval, r1 - r0, n, r0, padmap, max_rows * world)
+        splits = None
+        if partition == "contiguous":
+            splits = balanced_row_splits(counts, world)
+            padmap, max_rows = pad_index_map(splits)
+            pad = torch.from_numpy(padmap)
+            rows = torch.arange(splits[rank], splits[rank + 1], dtype=torch.int64)
+        elif partition == "degree_cyclic":
+            order, max_rows = degree_cyclic_deal(counts, world)
+            k = torch.arange(n, dtype=torch.int64)
+            pad = torch.empty(n, dtype=torch.int64)
+            pad[order] = (k % world) * max_rows + k // world
+            rows = order[rank::world].clone()
         else:
-            local = _LocalBlock.build(lrow, lcol, lval, n, r0, r1, padmap, max_rows * world, device)
-        return cls(local, splits, rank, world, n, global_nnz, global_max_degree, group)
+            raise ValueError(f"unknown partition {partition!r}")
+        # in the padded index space a rank's rows are the contiguous range
+        # [rank * max_rows, rank * max_rows + n_local)
+        pad = pad.to(row.device)
+        prow = pad[row]
+        r0 = rank * max_rows
+        mine = (prow >= r0) & (prow < r0 + rows.numel())
+        lrow, lcol = prow[mine], pad[col[mine]]
+        lval = None if val is None else torch.as_tensor(val)[mine]
+        n_pad = max_rows * world
+        if local_factory is not None:
+            local = local_factory(lrow, lcol, lval, int(rows.numel()), n_pad, r0)
+        else:
+            local = _LocalBlock.build(lrow, lcol, lval, n_pad, r0, r0 + int(rows.numel()), device)
+        return cls(local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group, splits)
 
     # ------------------------------------------------------------------ apply
     def _buffers(self, F, device, dtype):
@@ -175,7 +216,7 @@ class PartitionedAdj:
         order = int(order)
         if order <= 0:
             return X_local
-        rows = self.row_end - self.row_begin
+        rows = self.n_local
         if X_local.shape[0] != rows:
             raise ValueError(f"rank {self.rank} owns {rows} rows, got {X_local.shape[0]}")
         F = X_local.shape[1]
@@ -203,7 +244,7 @@ class PartitionedAdj:
 
     def _propagate_sliced(self, X_local, order, slices):
         """Feature-sliced pipeline: exchange slice s+1 while slice s is multiplied."""
-        rows = self.row_end - self.row_begin
+        rows = self.n_local
         F = X_local.shape[1]
         dev = X_local.device
         bounds = [(F * s) // slices for s in range(slices + 1)]
@@ -258,24 +299,24 @@ class _LocalBlock:
         self._ws = {}
 
     @classmethod
-    def build(cls, lrow, lcol, lval, n, r0, r1, padmap, n_cols_padded, device):
-        # Build the block as an n x n matrix that holds only the local rows (the
-        # library's builder is square: it inserts the self-loops and computes the
-        # row degree), then cut the local rows out and remap the columns.
+    def build(cls, lrow, lcol, lval, n_pad, r0, r1, device):
+        # Rows and columns arrive in the padded index space.  Build the block as an
+        # n_pad x n_pad matrix that holds only the local rows (the library's builder is
+        # square: it inserts the self-loops and computes the row degree), then cut the
+        # local rows [r0, r1) out.
         full = NormAdj.from_coo(lrow.to(device), lcol.to(device), None if lval is None else lval.to(device),
-                                n, device)
+                                n_pad, device)
         rp = full.rowptr
         e0, e1 = int(rp[r0].item()), int(rp[r1].item())
         rowptr = (rp[r0:r1 + 1] - e0).contiguous()
-        pm = torch.from_numpy(padmap).to(device)
-        colidx = pm[full.colidx[e0:e1].long()].to(torch.int32).contiguous()
+        colidx = full.colidx[e0:e1].contiguous()
         vals = full.vals[e0:e1].contiguous()
         # weight structure of the local rows only (the other rows of `full` hold just their self-loop)
         from .norm_adj import weight_structure
-        unit, w_off, corr = weight_structure(r1 - r0, rowptr, full.colidx[e0:e1] - r0, vals)
+        unit, w_off, corr = weight_structure(r1 - r0, rowptr, colidx - r0, vals)
         block = NormAdj(r1 - r0, rowptr, colidx, vals, full.deg[r0:r1].contiguous(), full.dinv[r0:r1].contiguous(),
                         unit_weights=unit, w_off=w_off, corr=corr)
-        return cls(block, block.dinv, r1 - r0, n_cols_padded, int(padmap[r0]) if r1 > r0 else 0)
+        return cls(block, block.dinv, r1 - r0, n_pad, r0)
 
     def scale_rows_into(self, src, dst):
         lib = _lib.load()

@@ -24,17 +24,19 @@ def _free_port():
 
 
 class OracleBlock:
-    """CPU stand-in for the device row block: same interface, oracle arithmetic."""
+    """CPU stand-in for the device row block: same interface, oracle arithmetic.
+    Rows and columns arrive in the padded index space, where the rank's rows are the
+    range [r0, r0 + n_rows)."""
 
-    def __init__(self, lrow, lcol, lval, n_rows, n, r0, padmap, n_cols_padded):
+    def __init__(self, lrow, lcol, lval, n_rows, n_pad, r0):
         v = np.ones(lrow.numel(), np.float32) if lval is None else lval.numpy().astype(np.float32)
-        rowptr, colidx, vals, deg, dinv = orc.norm_csr(lrow.numpy() + r0, lcol.numpy(), v, n)
+        rowptr, colidx, vals, deg, dinv = orc.norm_csr(lrow.numpy(), lcol.numpy(), v, n_pad)
         e0, e1 = rowptr[r0], rowptr[r0 + n_rows]
         self.rowptr = (rowptr[r0:r0 + n_rows + 1] - e0).astype(np.int32)
-        self.colidx = padmap[colidx[e0:e1]].astype(np.int32)
+        self.colidx = colidx[e0:e1].astype(np.int32)
         self.vals = vals[e0:e1]
         self.dinv = dinv[r0:r0 + n_rows]
-        self.n_rows, self.n_cols = n_rows, n_cols_padded
+        self.n_rows, self.n_cols = n_rows, n_pad
 
     def scale_rows_into(self, src, dst):
         dst.copy_(src * torch.from_numpy(self.dinv)[:, None])
@@ -49,24 +51,28 @@ class OracleBlock:
         out.copy_(torch.from_numpy(y.astype(np.float32)))
 
 
-def _worker(rank, world, port, n, r, c, X, order, q):
+def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sgnn_amd.dist import PartitionedAdj
         padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, "cpu", rank, world,
-                                       local_factory=OracleBlock)
-        Xl = torch.from_numpy(X[padj.row_begin:padj.row_end].copy())
+                                       local_factory=OracleBlock, partition=partition)
+        rows = padj.rows.numpy()
+        if partition == "contiguous":
+            assert np.array_equal(rows, np.arange(padj.row_begin, padj.row_end))
+        Xl = torch.from_numpy(X[rows].copy())
         Y = padj.propagate(Xl, order)
-        q.put((rank, padj.row_begin, padj.row_end, Y.numpy()))
+        q.put((rank, rows, Y.numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,order", [(2, 1), (2, 2), (3, 3)])
-def test_row_partitioned_matches_single(world, order):
+@pytest.mark.parametrize("world,order,partition", [(2, 1, "degree_cyclic"), (2, 2, "degree_cyclic"),
+                                                   (3, 3, "degree_cyclic"), (3, 2, "contiguous")])
+def test_row_partitioned_matches_single(world, order, partition):
     from sgnn_amd.graphgen import symmetric_simple_numpy
     n, F = 700, 12
     r, c = symmetric_simple_numpy(n, 4000, seed=3)
@@ -76,7 +82,8 @@ def test_row_partitioned_matches_single(world, order):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, q)) for k in range(world)]
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, q, partition))
+             for k in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
@@ -85,11 +92,15 @@ def test_row_partitioned_matches_single(world, order):
         assert p.exitcode == 0
     Y = np.zeros_like(exp)
     covered = np.zeros(n, bool)
-    for rank, r0, r1, y in got:
-        Y[r0:r1] = y
-        assert not covered[r0:r1].any()
-        covered[r0:r1] = True
+    sizes = []
+    for rank, rows, y in got:
+        Y[rows] = y
+        assert not covered[rows].any()
+        covered[rows] = True
+        sizes.append(rows.size)
     assert covered.all()
+    if partition == "degree_cyclic":
+        assert max(sizes) - min(sizes) <= 1                 # no padding to speak of in the exchange
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
 
 
@@ -103,9 +114,10 @@ def _grid_worker(rank, world, fg, port, n, r, c, X, order, q):
         group = make_row_groups(world, fg)
         padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, "cpu", row_rank, row_world,
                                        group=group, local_factory=OracleBlock)
-        Xl = torch.from_numpy(X[padj.row_begin:padj.row_end, f0:f1].copy())
+        rows = padj.rows.numpy()
+        Xl = torch.from_numpy(X[rows][:, f0:f1].copy())
         Y = padj.propagate(Xl, order)
-        q.put((rank, padj.row_begin, padj.row_end, f0, f1, Y.numpy()))
+        q.put((rank, rows, f0, f1, Y.numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -133,9 +145,9 @@ def test_feature_by_row_grid_matches_single(world, fg, order):
         assert p.exitcode == 0
     Y = np.zeros_like(exp)
     covered = np.zeros((n, F), np.int32)
-    for rank, r0, r1, f0, f1, y in got:
-        Y[r0:r1, f0:f1] = y
-        covered[r0:r1, f0:f1] += 1
+    for rank, rows, f0, f1, y in got:
+        Y[rows, f0:f1] = y
+        covered[rows, f0:f1] += 1
     assert (covered == 1).all()
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
 
@@ -175,3 +187,20 @@ def test_balanced_splits_and_padding():
         assert (m[s[p]:s[p + 1]] == p * max_rows + np.arange(s[p + 1] - s[p])).all()
     assert balanced_row_splits(np.ones(5), 1) == [0, 5]
     assert balanced_row_splits(np.ones(2), 4)[-1] == 2     # more ranks than rows: empty blocks allowed
+
+
+def test_degree_cyclic_deal_balances_rows_and_entries():
+    from sgnn_amd.dist import degree_cyclic_deal
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    n = 5000
+    r, c = symmetric_simple_numpy(n, 60_000, seed=8)
+    counts = np.bincount(r, minlength=n) + 1
+    for world in (2, 4, 8):
+        order, max_rows = degree_cyclic_deal(counts, world)
+        order = order.numpy()
+        assert np.array_equal(np.sort(order), np.arange(n)) and max_rows == -(-n // world)
+        assert (np.diff(counts[order]) <= 0).all()             # degree order
+        loads = [int(counts[order[p::world]].sum()) for p in range(world)]
+        sizes = [order[p::world].size for p in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+        assert max(loads) - min(loads) <= counts.max()          # within one row's entries of each other

@@ -28,10 +28,11 @@ def _worker(rank, world, port, n, r, c, X, order, slices, q, w=None):
         dev = torch.device("cuda:0")
         val = None if w is None else torch.full((r.size,), w, dtype=torch.float32)
         padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), val, n, dev, rank, world)
-        Xl = torch.from_numpy(X[padj.row_begin:padj.row_end].copy()).to(dev)
+        rows = padj.rows.numpy()
+        Xl = torch.from_numpy(X[rows].copy()).to(dev)
         Y = padj.propagate(Xl, order, slices=slices)
         torch.cuda.synchronize()
-        q.put((rank, padj.row_begin, padj.row_end, Y.cpu().numpy()))
+        q.put((rank, rows, Y.cpu().numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -59,8 +60,8 @@ def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w):
         p.join(timeout=60)
         assert p.exitcode == 0
     Y = np.zeros_like(exp)
-    for rank, r0, r1, y in got:
-        Y[r0:r1] = y
+    for rank, rows, y in got:
+        Y[rows] = y
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
 
 
