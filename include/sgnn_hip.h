@@ -249,6 +249,35 @@ int sgnn_sample_block_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, co
  */
 int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t* out, void* stream);
 
+/*
+ * Reconstruction loss of the graph auto-encoder layer on one batch (model/SGNN.py:138-164,
+ * 209-226, 682-702), in two launches around the caller's GEMM S = Z Z^T.
+ *
+ * sgnn_gae_targets_f32: for the batch `idx` (int64[b]) writes, dense b x b row-major,
+ *   target = A[idx][:, idx] with 0 where idx[i] == idx[j] (model/SGNN.py:167-170 on the
+ *            diagonal-free adjacency; the CSR passed may store A + I),
+ *   retain = 1 - max(random symmetric ignore mask without diagonal, overlook block)
+ *            (model/SGNN.py:157-159, 172-175, 209-226): a pair is ignored with
+ *            probability 2*mask_rate - mask_rate^2 (either of the reference's two draws),
+ *            drawn from `state` = uint64[2] {seed, counter} (counter advanced on the
+ *            stream, as in sgnn_batch_indices); the overlook matrix is its unit diagonal
+ *            plus, optionally, the pattern of a second CSR (overlook_rowptr/colidx, sorted
+ *            columns; both NULL = diagonal only),
+ *   row_pos[i] = sum_j target*retain, row_ret[i] = sum_j retain.
+ * sgnn_gae_loss_grad_f32: from S (row stride lds) and the four arrays above writes
+ *   G = dloss/dS (b x b) and row_loss[i] (the loss is their sum, added in row order) for
+ *   loss = mean(-ratio * target * log(max(P, 1e-6)) * retain) [if num_pos > 0]
+ *        + mean(-(1 - target) * log(max(1 - P, 1e-6)) * retain),
+ *   P = sigmoid(clamp(S, -40, 40)), num_pos = sum(row_pos), ratio = sum(row_ret)/num_pos - 1.
+ * The caller completes dZ = (G + G^T) Z.
+ */
+int sgnn_gae_targets_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                         const float* vals, const int32_t* overlook_rowptr, const int32_t* overlook_colidx,
+                         int64_t b, const int64_t* idx, float mask_rate, uint64_t* state,
+                         float* target, float* retain, float* row_pos, float* row_ret, void* stream);
+int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* target, const float* retain,
+                           const float* row_pos, const float* row_ret, float* G, float* row_loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

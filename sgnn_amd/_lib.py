@@ -52,6 +52,11 @@ SIGNATURES = {
                                        ctypes.c_float, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "sgnn_gae_targets_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+    "sgnn_gae_loss_grad_f32": (c_int, [c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
     "sgnn_batch_indices": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sgnn_sample_block_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                       c_void_p, c_int64, c_void_p]),

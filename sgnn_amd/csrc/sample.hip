@@ -118,3 +118,169 @@ extern "C" int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// Reconstruction loss of the graph auto-encoder layer on one batch, fused.
+//
+// Reference (model/SGNN.py:138-164, 209-226, 682-702), per optimiser iteration:
+// dense target block A_s = A[idx][:, idx]; ignore mask M = rand(b, b) <= rate made
+// symmetric, diagonal cleared, merged with the overlook block; retain = 1 - M;
+// P = sigmoid(clamp(Z Z^T, +-40));
+//   loss = mean(-ratio * A_s * log(max(P, 1e-6)) * retain)  [only if num_pos > 0]
+//        + mean(-(1 - A_s) * log(max(1 - P, 1e-6)) * retain),
+//   num_pos = sum(A_s * retain), ratio = sum(retain) / num_pos - 1.
+// That is ~60 elementwise / reduction kernels over b x b plus their backward.  Here:
+//   k_gae_targets  one workgroup per batch row: looks every A_s entry up in the CSR
+//                  (binary search, as k_sample_block), draws the ignore mask from a
+//                  counter-based hash of the unordered pair (one uniform per pair
+//                  against 2*rate - rate^2, the probability that either of the
+//                  reference's two draws masks it), applies the overlook entries, and
+//                  writes A_s, retain and the row's sums of A_s*retain and retain;
+//   k_gae_grad     elementwise over S = Z Z^T (computed by the caller's GEMM): the loss
+//                  terms and G = dloss/dS, with per-row loss sums.
+// The caller finishes with dZ = (G + G^T) Z.  Sums are per row, then added in row
+// order by every reader: results do not depend on scheduling.
+namespace {
+
+__device__ __forceinline__ float csr_lookup(const int* __restrict__ colidx, const float* __restrict__ vals, int lo0,
+                                            int hi0, int64_t want) {
+  int lo = lo0, hi = hi0;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (int64_t(colidx[mid]) < want) lo = mid + 1; else hi = mid;
+  }
+  if (lo < hi0 && int64_t(colidx[lo]) == want) return vals ? vals[lo] : 1.f;
+  return 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* __restrict__ rowptr,
+                                                     const int* __restrict__ colidx, const float* __restrict__ vals,
+                                                     const int* __restrict__ o_rowptr, const int* __restrict__ o_colidx,
+                                                     int64_t b, const int64_t* __restrict__ idx, float p_mask,
+                                                     const uint64_t* __restrict__ state, float* __restrict__ target,
+                                                     float* __restrict__ retain, float* __restrict__ row_pos,
+                                                     float* __restrict__ row_ret) {
+  const int64_t i = blockIdx.x;
+  const int64_t node = idx[i];
+  const bool ok = node >= 0 && node < n_rows;
+  const int lo0 = ok ? rowptr[node] : 0, hi0 = ok ? rowptr[node + 1] : 0;
+  const int olo = (ok && o_rowptr) ? o_rowptr[node] : 0, ohi = (ok && o_rowptr) ? o_rowptr[node + 1] : 0;
+  const uint32_t k0 = mix32(uint32_t(state[0]) ^ mix32(uint32_t(state[1]) + 0x9e3779b9u));
+  const uint32_t k1 = mix32(uint32_t(state[0] >> 32) + mix32(uint32_t(state[1] >> 32) ^ 0x85ebca6bu));
+  const uint32_t thresh = p_mask >= 1.f ? 0xffffffffu : uint32_t(double(p_mask) * 4294967296.0);
+  float s_pos = 0.f, s_ret = 0.f;
+  for (int64_t j = threadIdx.x; j < b; j += blockDim.x) {
+    const int64_t want = idx[j];
+    const bool self = want == node;
+    const float a = self ? 0.f : csr_lookup(colidx, vals, lo0, hi0, want);
+    // one uniform per unordered pair of batch positions
+    const uint32_t lo_ij = uint32_t(i < j ? i : j), hi_ij = uint32_t(i < j ? j : i);
+    const uint32_t u = mix32(mix32(lo_ij ^ k0) + hi_ij * 0x9e3779b9u + k1);
+    bool ignore = (i != j) && (p_mask > 0.f) && (u < thresh || p_mask >= 1.f);
+    if (self) ignore = true;                                            // the overlook matrix has a unit diagonal
+    else if (o_rowptr && csr_lookup(o_colidx, nullptr, olo, ohi, want) != 0.f) ignore = true;
+    const float r = ignore ? 0.f : 1.f;
+    target[i * b + j] = a;
+    retain[i * b + j] = r;
+    s_pos += a * r;
+    s_ret += r;
+  }
+  // block sum in a fixed order: lanes fold in halves, then the 4 wavefronts in order
+  __shared__ float sh[2][4];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s_pos += __shfl_down(s_pos, off);
+    s_ret += __shfl_down(s_ret, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s_pos;
+    sh[1][threadIdx.x >> 6] = s_ret;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    row_pos[i] = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+    row_ret[i] = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gae_grad(int64_t b, const float* __restrict__ S, int64_t lds,
+                                                  const float* __restrict__ target, const float* __restrict__ retain,
+                                                  const float* __restrict__ row_pos, const float* __restrict__ row_ret,
+                                                  float* __restrict__ G, float* __restrict__ row_loss) {
+  const int64_t i = blockIdx.x;
+  __shared__ float tot[2];
+  __shared__ float sh[4];
+  if (threadIdx.x < 2) {   // every workgroup adds the b row sums in the same order
+    const float* src = threadIdx.x == 0 ? row_pos : row_ret;
+    float t = 0.f;
+    for (int64_t r = 0; r < b; ++r) t += src[r];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const float num_pos = tot[0];
+  const float ratio = num_pos > 0.f ? tot[1] / num_pos - 1.f : 0.f;
+  const float inv = 1.f / (float(b) * float(b));
+  float loss = 0.f;
+  for (int64_t j = threadIdx.x; j < b; j += blockDim.x) {
+    const float s = S[i * lds + j];
+    const float sc = fminf(fmaxf(s, -40.f), 40.f);
+    const float p = 1.f / (1.f + expf(-sc));
+    const float a = target[i * b + j], r = retain[i * b + j];
+    const float q = 1.f - p;
+    float g = 0.f;
+    if (num_pos > 0.f) {
+      loss += -ratio * a * logf(fmaxf(p, 1e-6f)) * r;
+      if (p >= 1e-6f) g += -ratio * a * r * q;
+    }
+    loss += -(1.f - a) * logf(fmaxf(q, 1e-6f)) * r;
+    if (q >= 1e-6f) g += (1.f - a) * r * p;
+    if (!(s >= -40.f && s <= 40.f)) g = 0.f;   // outside the clamp nothing flows back
+    G[i * b + j] = g * inv;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) loss += __shfl_down(loss, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) row_loss[i] = (((sh[0] + sh[1]) + sh[2]) + sh[3]) * inv;
+}
+
+}  // namespace
+
+extern "C" int sgnn_gae_targets_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                                    const float* vals, const int32_t* overlook_rowptr,
+                                    const int32_t* overlook_colidx, int64_t b, const int64_t* idx, float mask_rate,
+                                    uint64_t* state, float* target, float* retain, float* row_pos, float* row_ret,
+                                    void* stream) {
+  using sgnn::fail;
+  if (n_rows < 0 || nnz < 0 || b < 0) return fail(SGNN_ERR_INVALID, "negative size");
+  if (!(mask_rate >= 0.f && mask_rate <= 1.f)) return fail(SGNN_ERR_INVALID, "mask_rate must lie in [0, 1]");
+  if (b == 0) return SGNN_OK;
+  if (b > 0x7fffffff) return fail(SGNN_ERR_INVALID, "batch larger than 2^31-1");
+  if (!rowptr || !idx || !state || !target || !retain || !row_pos || !row_ret || (nnz > 0 && !colidx))
+    return fail(SGNN_ERR_INVALID, "null pointer");
+  if ((overlook_rowptr == nullptr) != (overlook_colidx == nullptr))
+    return fail(SGNN_ERR_INVALID, "overlook rowptr and colidx go together");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float p = 2.f * mask_rate - mask_rate * mask_rate;   // either of the two draws masks the pair
+  hipLaunchKernelGGL(k_gae_targets, dim3(unsigned(b)), dim3(256), 0, st, n_rows, rowptr, colidx, vals, overlook_rowptr,
+                     overlook_colidx, b, idx, p, state, target, retain, row_pos, row_ret);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(1), 0, st, state);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+extern "C" int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* target,
+                                      const float* retain, const float* row_pos, const float* row_ret, float* G,
+                                      float* row_loss, void* stream) {
+  using sgnn::fail;
+  if (b < 0) return fail(SGNN_ERR_INVALID, "negative size");
+  if (b == 0) return SGNN_OK;
+  if (lds < b) return fail(SGNN_ERR_INVALID, "lds smaller than the block width");
+  if (!S || !target || !retain || !row_pos || !row_ret || !G || !row_loss)
+    return fail(SGNN_ERR_INVALID, "null pointer");
+  hipLaunchKernelGGL(k_gae_grad, dim3(unsigned(b)), dim3(256), 0, static_cast<hipStream_t>(stream), b, S, lds, target,
+                     retain, row_pos, row_ret, G, row_loss);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}

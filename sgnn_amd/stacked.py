@@ -241,12 +241,48 @@ class EmbeddingLayer(_Layer):
         return embedding.matmul(self.Wt).argmax(dim=1)
 
 
+class _FusedReconstruction(torch.autograd.Function):
+    """Reconstruction loss of one batch through ``sgnn_gae_targets_f32`` /
+    ``sgnn_gae_loss_grad_f32``: two kernels and a GEMM instead of ~60 elementwise and
+    reduction launches over the b x b block and their backward."""
+
+    @staticmethod
+    def forward(ctx, Z, adjacency, overlook, idx, mask_rate, state):
+        lib = _lib.load()
+        dev = Z.device
+        b = Z.shape[0]
+        Zc = Z.contiguous()
+        target = torch.empty((b, b), dtype=torch.float32, device=dev)
+        retain = torch.empty((b, b), dtype=torch.float32, device=dev)
+        sums = torch.empty((3, b), dtype=torch.float32, device=dev)          # row_pos, row_ret, row_loss
+        st = _lib.current_stream(dev)
+        _lib.check(lib.sgnn_gae_targets_f32(
+            adjacency.n, adjacency.nnz, _lib.ptr(adjacency.rowptr), _lib.ptr(adjacency.colidx), _lib.ptr(adjacency.vals),
+            None if overlook is None else _lib.ptr(overlook.rowptr),
+            None if overlook is None else _lib.ptr(overlook.colidx),
+            b, _lib.ptr(idx), float(mask_rate), _lib.ptr(state), _lib.ptr(target), _lib.ptr(retain),
+            _lib.ptr(sums[0]), _lib.ptr(sums[1]), st))
+        S = Zc.matmul(Zc.t())
+        G = torch.empty((b, b), dtype=torch.float32, device=dev)
+        _lib.check(lib.sgnn_gae_loss_grad_f32(b, _lib.ptr(S), b, _lib.ptr(target), _lib.ptr(retain), _lib.ptr(sums[0]),
+                                              _lib.ptr(sums[1]), _lib.ptr(G), _lib.ptr(sums[2]), st))
+        ctx.save_for_backward(Zc, G)
+        ctx.mark_non_differentiable(target, retain)
+        return sums[2].sum(), target, retain
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gt, _gr):
+        Z, G = ctx.saved_tensors
+        return grad_loss * (G + G.t()).matmul(Z), None, None, None, None, None
+
+
 class GAELayer(_Layer):
     """One decoupled graph auto-encoder layer (SingleLayerGAE, model/SGNN.py:120-251)."""
 
     def __init__(self, adjacency, input_dim, embedding_dim, p, device, overlook=None):
         super().__init__(adjacency, input_dim, embedding_dim, p, device)
         self.mask_rate = p.get(LayerParam.MASK_RATE, 0.0)
+        self.fused_loss = p.get("fused_loss", True)
         # entries to leave out of the reconstruction loss besides the diagonal: a
         # handle on the symmetric 0/1 overlook matrix, or None for "diagonal only"
         # (overlooked_rate 0: utils.py:47-51)
@@ -282,9 +318,13 @@ class GAELayer(_Layer):
         if train:
             def loss_fn():
                 idx = self._batch(PX.shape[0])
-                target = self.adjacency.sample_block(idx, skip_self=True)              # model/SGNN.py:167-170
                 emb = self(PX[idx])
-                loss = self.reconstruction_loss(self.decode(emb), target, 1 - self._ignore_mask(idx))
+                if self.fused_loss:
+                    loss = _FusedReconstruction.apply(emb, self.adjacency, self.overlook, idx, self.mask_rate,
+                                                      self._rng_state)[0]
+                else:
+                    target = self.adjacency.sample_block(idx, skip_self=True)          # model/SGNN.py:167-170
+                    loss = self.reconstruction_loss(self.decode(emb), target, 1 - self._ignore_mask(idx))
                 loss = loss + self.lam * self._lasso()
                 if embedding_target is not None:
                     loss = loss + eta * (emb - embedding_target[idx]).pow(2).sum() / emb.shape[0]

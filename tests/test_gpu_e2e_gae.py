@@ -91,3 +91,63 @@ def test_gae_with_overlooked_edges_and_loss_pieces(gpu_device):
                                         keep.to(gpu_device)).item()
     exp0 = (-torch.log(1 - r) * k).mean().item()
     assert abs(zero - exp0) <= 1e-5 * abs(exp0)
+
+
+def test_fused_reconstruction_matches_autograd(gpu_device):
+    """The fused loss kernels against the plain-torch statement of the same loss
+    (GAELayer.reconstruction_loss under autograd), fed the target and retain blocks the
+    kernels produced: loss and dloss/dZ within 1e-5 relative; the blocks themselves are
+    checked against the oracle's sub-adjacency and the reference's mask construction."""
+    import scipy.sparse as sp
+    from oracle import sgnn_oracle as orc
+    from sgnn_amd.norm_adj import NormAdj
+    from sgnn_amd.stacked import GAELayer, _FusedReconstruction
+    graph = load_golden("e2e_sgnn_planted.npz")
+    n = graph["X"].shape[0]
+    A = sp.coo_matrix((np.ones(graph["row"].size, np.float32), (graph["row"], graph["col"])), shape=(n, n)).tocsr()
+    adj = NormAdj.from_scipy(A, gpu_device)
+    rng = np.random.default_rng(0)
+    pick = rng.choice(A.nnz, 800, replace=False)
+    coo = A.tocoo()
+    look = NormAdj.from_coo(coo.row[pick], coo.col[pick], None, n, gpu_device, symmetrize=True, clamp_one=True,
+                            strip_diag=True)
+    L = look.to_scipy()
+    for b, d, rate, overlook in [(256, 32, 0.2, None), (200, 16, 0.0, look), (64, 8, 1.0, None), (300, 64, 0.35, look)]:
+        gen = torch.Generator().manual_seed(b)
+        idx = torch.randperm(n, generator=gen)[:b].to(gpu_device)
+        Z = (torch.randn(b, d, generator=gen) * (3.0 if b == 256 else 0.7)).to(gpu_device).requires_grad_(True)
+        state = torch.tensor([99, 5], dtype=torch.int64, device=gpu_device)
+        loss, target, retain = _FusedReconstruction.apply(Z, adj, overlook, idx, rate, state)
+        loss.backward()
+        got_grad = Z.grad.clone()
+        assert int(state[1]) == 6
+        i = idx.cpu().numpy()
+        assert np.array_equal(target.cpu().numpy(), orc.sample_block(A, i))            # diagonal-free A
+        R = retain.cpu().numpy()
+        assert np.array_equal(R, R.T) and not R.diagonal().any() and set(np.unique(R)) <= {0.0, 1.0}
+        off = ~np.eye(b, dtype=bool)
+        if overlook is not None:
+            Ls = orc.sample_block(L, i)
+            assert not R[(Ls > 0) & off].any()
+            free = off & (Ls == 0)
+        else:
+            free = off
+        expect_keep = (1 - rate) ** 2                                                  # neither draw masks the pair
+        assert abs(R[free].mean() - expect_keep) <= 0.02, (R[free].mean(), expect_keep)
+        # same loss under autograd
+        Z2 = Z.detach().clone().requires_grad_(True)
+        rec = torch.sigmoid(Z2.matmul(Z2.t()).clamp(-40.0, 40.0))
+        ref = GAELayer.reconstruction_loss(rec, target, retain)
+        ref.backward()
+        assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-7
+        err = (got_grad - Z2.grad).norm() / Z2.grad.norm().clamp_min(1e-12)
+        assert float(err) <= 1e-5, float(err)
+    # same (seed, counter) -> same mask; next counter -> another one
+    s1 = torch.tensor([1, 0], dtype=torch.int64, device=gpu_device)
+    s2 = torch.tensor([1, 0], dtype=torch.int64, device=gpu_device)
+    Z = torch.randn(128, 8, device=gpu_device)
+    idx = torch.arange(128, device=gpu_device)
+    r1 = _FusedReconstruction.apply(Z, adj, None, idx, 0.3, s1)[2]
+    r2 = _FusedReconstruction.apply(Z, adj, None, idx, 0.3, s2)[2]
+    r3 = _FusedReconstruction.apply(Z, adj, None, idx, 0.3, s2)[2]
+    assert torch.equal(r1, r2) and not torch.equal(r2, r3)
