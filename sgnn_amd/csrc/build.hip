@@ -106,6 +106,7 @@ __global__ void k_merge_runs(int64_t m, int64_t nnz_src, int64_t nnz_in, const u
   }
   float s = 0.0f, s_mirror = 0.0f;
   bool any = false, open = true;  // open: the input part of the run has not been closed yet
+  bool loop_added = false;
   // REMAINING: a diagonal run keeps the weight of its last input entry (torch_geometric
   // assigns loop weights by index, so later entries overwrite earlier ones), 1 if it has none
   const bool assign = self_loops == SGNN_LOOPS_REMAINING && (key >> cbits) == (key & ((uint64_t(1) << cbits) - 1));
@@ -126,12 +127,17 @@ __global__ void k_merge_runs(int64_t m, int64_t nnz_src, int64_t nnz_in, const u
       any = true;
     } else {
       close();  // the marker is the last entry of its run
-      if (self_loops == SGNN_LOOPS_ADD || !any) s += 1.0f;
+      if (self_loops == SGNN_LOOPS_ADD || !any) {
+        s += 1.0f;
+        loop_added = true;
+      }
     }
   }
   if (open) close();
   rsum[i] = s;
-  keep[i] = (drop_zeros && s == 0.0f) ? 0u : 1u;
+  // zero-dropping applies to the merged input (what scipy's sparse arithmetic removes);
+  // an entry the self-loop was added to stays, even if -1 + 1 made it 0
+  keep[i] = (drop_zeros && s == 0.0f && !loop_added) ? 0u : 1u;
 }
 
 __global__ void k_scatter(int64_t m, const uint64_t* __restrict__ keys, const float* __restrict__ rsum,
