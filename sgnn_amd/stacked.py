@@ -192,11 +192,25 @@ class _Layer(torch.nn.Module):
                 step()
         cur.wait_stream(side)
         opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        for _ in range(self.max_iter - self.GRAPH_WARMUP - 1):
-            graph.replay()
+        done = self.GRAPH_WARMUP
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            done += 1
+        except RuntimeError as exc:
+            # an activation or loss the caller plugged in may not be capturable; the
+            # iterations are then issued one by one (same arithmetic, more launch overhead)
+            import warnings
+            warnings.warn(f"HIP graph capture of the optimiser iteration failed ({exc}); running eagerly")
+            self.use_graph = False
+            graph = None
+        for _ in range(self.max_iter - done):
+            if graph is not None:
+                graph.replay()
+            else:
+                opt.zero_grad(set_to_none=True)
+                step()
 
     def _finish(self, X, PX):
         with torch.no_grad():
