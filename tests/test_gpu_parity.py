@@ -403,3 +403,40 @@ def test_gcnconv_backward_vs_dense_autograd(dev):
     assert rel_err(x.grad.cpu().numpy(), xd.grad.numpy()) <= TOL
     assert rel_err(gcn.lin.weight.grad.cpu().numpy(), W.grad.numpy()) <= 1e-4     # dense fp32 GEMM on top
     assert rel_err(gcn.bias.grad.cpu().numpy(), b.grad.numpy()) <= 1e-4
+
+
+def test_rowgroup_entry_point_rejects_what_it_cannot_run(dev):
+    """Direct C-ABI calls: unaligned X, in-kernel column scaling, short workspace and
+    mismatched item counts are refused with a message, nothing is launched."""
+    from sgnn_amd import _lib
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    lib = _lib.load()
+    n, F = 2000, 200
+    r, c = symmetric_simple_numpy(n, 30_000, seed=12)
+    adj = _na().from_coo(r, c, None, n, dev)
+    plan = adj._rowgroup_plan(F)
+    assert plan is not None
+    X = torch.randn(n, F + 4, device=dev)
+    Y = torch.empty(n, F, device=dev)
+    ws = adj._rowgroup_ws(plan, F)
+    st = _lib.current_stream(dev)
+
+    def call(x_ptr, ldx, dinv_col=None, items=plan["items"], ws_bytes=ws.numel()):
+        return lib.sgnn_spmm_rowgroup_f32(n, n, adj.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
+                                          items, plan["slots"], plan["n_long"], _lib.ptr(adj.dinv), dinv_col,
+                                          1.0, None, 0, x_ptr, ldx, _lib.ptr(Y), F, 0, _lib.ptr(ws), ws_bytes, st)
+    assert call(X.data_ptr(), F + 4) == 0
+    assert call(X.data_ptr() + 4, F + 4) == -4 and b"16-byte" in lib.sgnn_last_error()       # base off by one float
+    assert call(X.data_ptr(), F + 3) == -4                                                     # odd row stride
+    assert call(X.data_ptr(), F + 4, dinv_col=_lib.ptr(adj.dinv)) == -4 and b"scaled" in lib.sgnn_last_error()
+    assert call(X.data_ptr(), F + 4, items=plan["items"] * 100 + 7) == -1
+    if plan["slots"] > 0:
+        assert call(X.data_ptr(), F + 4, ws_bytes=16) == -2
+    assert call(X.data_ptr(), F - 1) == -1                                                     # ldx < F
+    torch.cuda.synchronize()
+    # the Python layer stages such inputs itself: an unaligned view gives the same result as a copy
+    Xu = X[:, 1:F + 1]
+    assert Xu.data_ptr() % 16 != 0
+    a = adj.spmm(Xu)
+    b = adj.spmm(Xu.contiguous())
+    assert torch.equal(a, b)
