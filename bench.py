@@ -14,7 +14,8 @@ block of rows of the graph and a slice of the feature columns, and all-gathers t
 scaled row blocks of its slice over RCCL before its SpMM.  Feature slices need no
 exchange at all, row blocks keep the rows wide; which grid is fastest depends on
 the xGMI all-gather rate, so with ``--feature-groups 0`` (default) every grid that
-divides N is timed for a few untimed steps and the fastest is benchmarked.
+divides N (and, for grids that exchange, both the plain and the overlapped schedule)
+is timed for a few untimed steps and the fastest is benchmarked.
 """
 from __future__ import annotations
 
@@ -145,7 +146,8 @@ def main():
         from sgnn_amd.dist import PartitionedAdj, grid_layout, make_row_groups
 
         def build_grid(fg):
-            """Everything one candidate grid needs: (step function, info)."""
+            """One candidate grid: a list of (step function, info), one entry per exchange
+            schedule that reproduces the plain one on this machine."""
             row_rank, row_world, fgroup, f0, f1 = grid_layout(rank, world, fg, F)
             group = make_row_groups(world, fg)
             t0 = time.perf_counter()
@@ -153,27 +155,31 @@ def main():
             torch.cuda.synchronize()
             build_ms = (time.perf_counter() - t0) * 1e3
             Xl = X[padj.rows.to(device)][:, f0:f1].contiguous()
-            # the overlapped (feature-sliced) exchange is used only if it reproduces the
-            # plain one on this machine; every rank of the job takes the same decision
-            slices = max(1, args.slices) if row_world > 1 else 1
-            ok = torch.ones(1, device=device)
-            if slices > 1:
+            schedules = [1]
+            want = max(1, args.slices)
+            if row_world > 1 and want > 1:
+                # the overlapped (feature-sliced) exchange competes only if it reproduces
+                # the plain one; every rank of the job takes the same decision
+                ok = torch.ones(1, device=device)
                 try:
                     a = padj.propagate(Xl, args.order, slices=1)
-                    b = padj.propagate(Xl, args.order, slices=slices)
+                    b = padj.propagate(Xl, args.order, slices=want)
                     if not torch.allclose(a, b, rtol=1e-4, atol=1e-5):
                         ok.zero_()
                     del a, b
                 except Exception as exc:          # noqa: BLE001
                     print(f"[rank {rank}] sliced schedule failed: {exc}", file=sys.stderr, flush=True)
                     ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 0:
-                slices = 1
-            info = {"feature_groups": fg, "row_ranks": row_world, "features_per_rank": f1 - f0,
-                    "exchange_slices": slices,
-                    "adjacency_build_ms": build_ms, "nnz": padj.global_nnz, "max_deg": padj.global_max_degree}
-            return (lambda: padj.propagate(Xl, args.order, slices=slices)), info
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() != 0:
+                    schedules.append(want)
+            out = []
+            for sl in schedules:
+                info = {"feature_groups": fg, "row_ranks": row_world, "features_per_rank": f1 - f0,
+                        "exchange_slices": sl, "adjacency_build_ms": build_ms, "nnz": padj.global_nnz,
+                        "max_deg": padj.global_max_degree}
+                out.append(((lambda sl=sl: padj.propagate(Xl, args.order, slices=sl)), info))
+            return out
 
         def probe(step_fn, reps=3):
             for _ in range(2):
@@ -194,23 +200,26 @@ def main():
             candidates = [g for g in range(1, world + 1) if world % g == 0 and g <= F]
         best = None
         probed = {}
+        n_options = 0
         for fg in candidates:
-            step_fn, info = build_grid(fg)
-            t = probe(step_fn) if len(candidates) > 1 else 0.0
-            probed[str(fg)] = round(t * 1e3, 3)
-            if rank == 0:
-                print(f"[bench] grid {fg} feature slices x {world // fg} row blocks: built in "
-                      f"{info['adjacency_build_ms']:.0f} ms, probe {t * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
-            if best is None or t < best[0]:
-                best = (t, step_fn, info)
-            else:
+            for step_fn, info in build_grid(fg):
+                n_options += 1
+                t = probe(step_fn)
+                tag = f"{fg}x{world // fg}" + (f"/s{info['exchange_slices']}" if info["exchange_slices"] > 1 else "")
+                probed[tag] = round(t * 1e3, 3)
+                if rank == 0:
+                    print(f"[bench] {fg} feature slices x {world // fg} row blocks, exchange in "
+                          f"{info['exchange_slices']} slice(s): built in {info['adjacency_build_ms']:.0f} ms, "
+                          f"probe {t * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
+                if best is None or t < best[0]:
+                    best = (t, step_fn, info)
                 del step_fn
             torch.cuda.empty_cache()
         _, step, info = best
         del row, col, X
         nnz, max_deg = info.pop("nnz"), info.pop("max_deg")
         extra.update(info)
-        if len(candidates) > 1:
+        if n_options > 1:
             extra["grid_probe_ms"] = probed
 
     lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
