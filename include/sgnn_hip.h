@@ -194,6 +194,14 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                        corr[i] = (diagonal value of row i) - w_off where the row stores
  *                        a diagonal entry, else 0; x'_i is row (i + x_row_offset) of X.
  *                        Unit weights: w_off = 1, corr = NULL.
+ * sgnn_rowgroup_weights  for adjacencies whose stored values differ (edge weights passed
+ *                        to GCNConv, weighted scipy matrices): fills `group_weights`
+ *                        (device, sgnn_rowgroup_weights_bytes(merged, R)) with the value of
+ *                        every (merged column, row of the group) pair, 0 where the row has
+ *                        no such entry.  Passed to sgnn_spmm_rowgroup_f32 it makes the
+ *                        kernel compute the weighted sum entry by entry (fmaf in ascending
+ *                        column order per row); w_off and corr are then ignored.  NULL =
+ *                        pattern sum + uniform-weight epilogue as described above.
  * No reference counterpart for the plan itself: the reference keeps only the
  * COO tensor (utils.py:54-62).
  */
@@ -205,8 +213,13 @@ int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz,
                         void* plan, size_t plan_bytes,
                         void* workspace, size_t workspace_bytes, void* stream);
 size_t sgnn_spmm_rowgroup_workspace_bytes(int64_t slots, int R, int64_t F);
+size_t sgnn_rowgroup_weights_bytes(int64_t merged, int R);
+int sgnn_rowgroup_weights(int64_t n_rows, int64_t nnz,
+                          const int32_t* rowptr, const int32_t* colidx, const float* vals, int R,
+                          const void* plan, size_t plan_bytes, int64_t merged,
+                          float* group_weights, size_t group_weights_bytes, void* stream);
 int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, int R,
-                           const void* plan, size_t plan_bytes,
+                           const void* plan, size_t plan_bytes, const float* group_weights,
                            int64_t items, int64_t slots, int64_t n_long,
                            const float* dinv_row, const float* dinv_col,
                            float w_off, const float* corr, int64_t x_row_offset,

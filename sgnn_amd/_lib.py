@@ -47,7 +47,10 @@ SIGNATURES = {
     "sgnn_rowgroup_build": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                     c_void_p, c_size_t, c_void_p]),
     "sgnn_spmm_rowgroup_workspace_bytes": (c_size_t, [c_int64, c_int, c_int64]),
-    "sgnn_spmm_rowgroup_f32": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t,
+    "sgnn_rowgroup_weights_bytes": (c_size_t, [c_int64, c_int]),
+    "sgnn_rowgroup_weights": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                      c_int64, c_void_p, c_size_t, c_void_p]),
+    "sgnn_spmm_rowgroup_f32": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p,
                                        c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                        ctypes.c_float, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),

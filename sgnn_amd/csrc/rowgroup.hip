@@ -348,12 +348,40 @@ __global__ void k_item_deal(int64_t cap_items, const int64_t* __restrict__ count
   d[pos] = tmp[3 * cap_items + src];
 }
 
+// Dense per-column weights for graphs whose stored values differ: gw[m][r] = value of the
+// entry (row r of the group, merged column m), 0 where the row has no such entry.  One
+// wavefront per (group, row of the group): its lanes take the row's CSR entries and look
+// each column up in the group's sorted merged list.
+__global__ __launch_bounds__(256) void k_fill_weights(int64_t slots, int R, const int32_t* __restrict__ grows,
+                                                      const int32_t* __restrict__ gptr, const int32_t* __restrict__ gcol,
+                                                      const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ colidx, const float* __restrict__ vals,
+                                                      float* __restrict__ gw) {
+  const int64_t s = blockIdx.x * int64_t(blockDim.x / kWave) + threadIdx.x / kWave;
+  if (s >= slots) return;
+  const int row = grows[s];
+  if (row < 0) return;
+  const int64_t g = s / R;
+  const int r = int(s % R);
+  const int lo0 = gptr[g], hi0 = gptr[g + 1];
+  for (int e = rowptr[row] + int(threadIdx.x & (kWave - 1)); e < rowptr[row + 1]; e += kWave) {
+    const int c = colidx[e];
+    int lo = lo0, hi = hi0;
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (gcol[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    gw[int64_t(lo) * R + r] = vals[e];   // the column is in the list by construction
+  }
+}
+
 // ---- the kernel ------------------------------------------------------------------
 struct RgArgs {
   const int32_t *grows, *gptr, *gcol;
   const uint32_t* gmask;
   const int32_t *item_group, *item_m0, *item_m1, *item_out, *long_group, *long_slot;
   const float *dinv_row, *X, *corr;
+  const float* gw;   // [merged][R] weight of (merged column, row of the group), NULL: pattern only
   float *Y, *partial;
   int64_t ldx, ldy, x_bytes, x_row_offset;
   float w_off;
@@ -376,9 +404,16 @@ struct Lay {
 };
 
 // Issue the fetches of UU consecutive merged columns (lanes k .. k+UU-1 of `cols`).
-template <class L, int C4, int C2, int C1, int UU, bool BIGX>
-__device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t cols, int k, int lane,
-                                        float (&xv)[UU][L::NF]) {
+// With weights (HASW) the R weights of each of the UU columns follow: they are stored
+// [merged column][row of the group], so one coalesced load by the first UU*R lanes brings
+// the whole step's weights (`mabs` = index of the step's first column in the merged list).
+template <class L, int R, int C4, int C2, int C1, int UU, bool BIGX, bool HASW>
+__device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t cols, int k, int lane, int64_t mabs,
+                                        float (&xv)[UU][L::NF], float& wv) {
+  if constexpr (HASW) {
+    static_assert(UU * R <= kWave, "a step's weights must fit one wavefront-wide load");
+    wv = lane < UU * R ? a.gw[mabs * R + lane] : 0.0f;
+  }
 #pragma unroll
   for (int u = 0; u < UU; ++u) {
     const int32_t col = __builtin_amdgcn_readlane(cols, k + u);
@@ -414,8 +449,9 @@ __device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t col
 // indexed accumulator was tried: the compiler folds the tree's leaves into one
 // dynamically indexed access and moves the accumulators to scratch memory; with the
 // fold blocked the kernel needs 386 registers, one wavefront per SIMD.)
-template <int R, int NF, int UU>
-__device__ __forceinline__ void rg_accum(uint32_t masks, int k, const float (&xv)[UU][NF], float (&acc)[R][NF]) {
+template <int R, int NF, int UU, bool HASW>
+__device__ __forceinline__ void rg_accum(uint32_t masks, int k, const float (&xv)[UU][NF], float wv,
+                                         float (&acc)[R][NF]) {
 #pragma unroll
   for (int u = 0; u < UU; ++u) {
     const uint32_t mk = uint32_t(__builtin_amdgcn_readlane(int(masks), k + u));
@@ -425,8 +461,14 @@ __device__ __forceinline__ void rg_accum(uint32_t masks, int k, const float (&xv
 #pragma unroll
         for (int r = q; r < q + 4; ++r)
           if (mk & (1u << r)) {
+            if constexpr (HASW) {
+              const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), u * R + r));
 #pragma unroll
-            for (int i = 0; i < NF; ++i) acc[r][i] += xv[u][i];
+              for (int i = 0; i < NF; ++i) acc[r][i] = fmaf(w, xv[u][i], acc[r][i]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < NF; ++i) acc[r][i] += xv[u][i];
+            }
           }
       }
   }
@@ -439,7 +481,9 @@ __device__ __forceinline__ void rg_accum(uint32_t masks, int k, const float (&xv
 // w_off = 1 and corr = NULL.  Then the row scaling of utils.py:95.
 __device__ __forceinline__ float rg_epilogue(const RgArgs& a, float s, int row, int f, bool scale, float dr) {
   float y = s;
-  if (a.corr != nullptr) {
+  if (a.gw != nullptr) {
+    // the weights were applied entry by entry
+  } else if (a.corr != nullptr) {
     const int64_t xr = int64_t(row) + a.x_row_offset;
     y = fmaf(a.w_off, y, a.corr[row] * a.X[xr * a.ldx + f]);
   } else if (a.w_off != 1.0f) {
@@ -525,7 +569,7 @@ __device__ __forceinline__ void rg_write_rows(const RgArgs& a, const float (&acc
 // Merged columns are taken 64 at a time through a VGPR (ids and masks) and handed to
 // the scalar unit by v_readlane; every row of a group is summed in ascending column
 // order.
-template <int R, int C4, int C2, int C1, int U, bool BIGX>
+template <int R, int C4, int C2, int C1, int U, bool BIGX, bool HASW>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
   using L = Lay<C4, C2, C1>;
   constexpr int NF = L::NF;
@@ -557,7 +601,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
   // at least U columns.  Every batch but an item's last is full and 64 / U is even,
   // so an odd number of full steps can only occur in the last batch.
   float xa[U][NF], xb[U][NF];
-  if (min(kWave, m1 - m0) >= U) rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, ncols, 0, lane, xa);
+  float wa = 0.0f, wb = 0.0f;
+  if (min(kWave, m1 - m0) >= U) rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, ncols, 0, lane, m0, xa, wa);
   for (int m = m0; m < m1; m += kWave) {
     const int32_t cols = ncols;
     const uint32_t masks = nmask;
@@ -572,20 +617,21 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
     const bool next_full_step = more && (m1 - (m + kWave)) >= U;
     int k = 0;
     for (; k + 2 * U <= nfull; k += 2 * U) {
-      rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, cols, k + U, lane, xb);
-      rg_accum<R, NF, U>(masks, k, xa, acc);
-      if (k + 2 * U < nfull) rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, cols, k + 2 * U, lane, xa);
-      else if (next_full_step) rg_load<L, C4, C2, C1, U, BIGX>(a, rsrc, ncols, 0, lane, xa);
-      rg_accum<R, NF, U>(masks, k + U, xb, acc);
+      rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, cols, k + U, lane, m + k + U, xb, wb);
+      rg_accum<R, NF, U, HASW>(masks, k, xa, wa, acc);
+      if (k + 2 * U < nfull) rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, cols, k + 2 * U, lane, m + k + 2 * U, xa, wa);
+      else if (next_full_step) rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, ncols, 0, lane, m + kWave, xa, wa);
+      rg_accum<R, NF, U, HASW>(masks, k + U, xb, wb, acc);
     }
     if (k < nfull) {   // odd count of full steps: last batch only, xa holds the step
-      rg_accum<R, NF, U>(masks, k, xa, acc);
+      rg_accum<R, NF, U, HASW>(masks, k, xa, wa, acc);
       k += U;
     }
     for (; k < cnt; ++k) {
       float x1[1][NF];
-      rg_load<L, C4, C2, C1, 1, BIGX>(a, rsrc, cols, k, lane, x1);
-      rg_accum<R, NF, 1>(masks, k, x1, acc);
+      float w1 = 0.0f;
+      rg_load<L, R, C4, C2, C1, 1, BIGX, HASW>(a, rsrc, cols, k, lane, m + k, x1, w1);
+      rg_accum<R, NF, 1, HASW>(masks, k, x1, w1, acc);
     }
   }
   rg_write_rows<R, C4, C2, C1>(a, acc, g, out, lane);
@@ -630,9 +676,16 @@ int launch_rg(const RgArgs& a, hipStream_t st) {
   // row fetches in flight per wavefront and buffer: about 8-10 registers' worth of loads
   constexpr int NF = Lay<C4, C2, C1>::NF;
   constexpr int U = NF <= 2 ? 8 : (NF <= 4 ? 4 : 2);
+  constexpr int UW = U * R <= kWave ? U : kWave / R;   // with weights: a step's U*R weights in one load
   const dim3 grid(unsigned((a.items + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWave * kWavesPerBlock);
-  if (a.x_bytes >= (int64_t(1) << 32)) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, true>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, false>), grid, block, 0, st, a);
+  const bool bigx = a.x_bytes >= (int64_t(1) << 32);
+  if (a.gw != nullptr) {
+    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, false, true>), grid, block, 0, st, a);
+  } else {
+    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, false, false>), grid, block, 0, st, a);
+  }
   HIP_TRY(hipGetLastError());
   if (a.n_long > 0) {
     hipLaunchKernelGGL(k_rg_combine<R>, dim3(unsigned(a.n_long), R), dim3(256), 0, st, a);
@@ -810,8 +863,33 @@ size_t sgnn_spmm_rowgroup_workspace_bytes(int64_t slots, int R, int64_t F) {
   return align_up(size_t(slots) * size_t(R) * size_t(F) * 4 + 256);
 }
 
+size_t sgnn_rowgroup_weights_bytes(int64_t merged, int R) {
+  if (merged < 0 || (R != 8 && R != 16)) return 0;
+  return align_up(size_t(merged) * size_t(R) * sizeof(float) + 256);
+}
+
+int sgnn_rowgroup_weights(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                          const float* vals, int R, const void* plan, size_t plan_bytes, int64_t merged,
+                          float* group_weights, size_t group_weights_bytes, void* stream) {
+  if (n_rows <= 0 || nnz <= 0 || merged <= 0) return fail(SGNN_ERR_INVALID, "empty matrix");
+  if (R != 8 && R != 16) return fail(SGNN_ERR_INVALID, "R must be 8 or 16");
+  if (!rowptr || !colidx || !vals || !plan || !group_weights) return fail(SGNN_ERR_INVALID, "null pointer");
+  Plan p = carve_plan(const_cast<void*>(plan), n_rows, nnz, R);
+  if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "row-group plan buffer too small");
+  if (merged > nnz || group_weights_bytes < size_t(merged) * size_t(R) * sizeof(float))
+    return fail(SGNN_ERR_WORKSPACE, "group weight buffer too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(group_weights, 0, size_t(merged) * size_t(R) * sizeof(float), st));
+  const int64_t slots = p.G * R;
+  hipLaunchKernelGGL(k_fill_weights, dim3(unsigned((slots + 3) / 4)), dim3(256), 0, st, slots, R, p.grows, p.gptr,
+                     p.gcol, rowptr, colidx, vals, group_weights);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
 int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, int R, const void* plan,
-                           size_t plan_bytes, int64_t items, int64_t slots, int64_t n_long, const float* dinv_row,
+                           size_t plan_bytes, const float* group_weights, int64_t items, int64_t slots,
+                           int64_t n_long, const float* dinv_row,
                            const float* dinv_col, float w_off, const float* corr, int64_t x_row_offset,
                            const float* X, int64_t ldx, float* Y, int64_t ldy, int epilogue,
                            void* workspace, size_t workspace_bytes, void* stream) {
@@ -838,6 +916,7 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   a.item_group = p.item_group; a.item_m0 = p.item_m0; a.item_m1 = p.item_m1; a.item_out = p.item_out;
   a.long_group = p.long_group; a.long_slot = p.long_slot;
   a.dinv_row = dinv_row; a.partial = static_cast<float*>(workspace);
+  a.gw = group_weights;
   a.w_off = w_off; a.corr = corr; a.x_row_offset = x_row_offset;
   if (corr && (x_row_offset < 0 || x_row_offset + n_rows > n_cols))
     return fail(SGNN_ERR_INVALID, "x_row_offset places the block's own rows outside X");

@@ -326,7 +326,7 @@ class _LocalBlock:
 
     def _plan(self, F):
         a = self.adj
-        if a.w_off is None or a.nnz == 0:
+        if a.nnz == 0:
             return None
         lib = _lib.load()
         R = lib.sgnn_rowgroup_config(F)
@@ -343,7 +343,14 @@ class _LocalBlock:
                                                R, _lib.ptr(buf), pbytes, _lib.ptr(ws), wbytes,
                                                _lib.current_stream(dev)))
             merged, items, slots, n_long = (int(v) for v in buf[:32].view(torch.int64).cpu())
-            plan = dict(R=R, buf=buf, bytes=pbytes, items=items, slots=slots, n_long=n_long)
+            gw = None
+            if a.w_off is None:         # stored values differ: per-entry weights ride with the plan
+                gbytes = lib.sgnn_rowgroup_weights_bytes(merged, R)
+                gw = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+                _lib.check(lib.sgnn_rowgroup_weights(self.n_rows, a.nnz, _lib.ptr(a.rowptr), _lib.ptr(a.colidx),
+                                                     _lib.ptr(a.vals), R, _lib.ptr(buf), pbytes, merged,
+                                                     _lib.ptr(gw), gbytes, _lib.current_stream(dev)))
+            plan = dict(R=R, buf=buf, bytes=pbytes, items=items, slots=slots, n_long=n_long, gw=gw)
             self._plans[R] = plan
         return plan
 
@@ -364,8 +371,8 @@ class _LocalBlock:
                 self._ws[("rg", F)] = ws
             _lib.check(lib.sgnn_spmm_rowgroup_f32(
                 self.n_rows, self.n_cols, a.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
-                plan["items"], plan["slots"], plan["n_long"], _lib.ptr(self.dinv), None,
-                float(a.w_off), _lib.ptr(a.corr), self.x_row_offset,
+                _lib.ptr(plan["gw"]), plan["items"], plan["slots"], plan["n_long"], _lib.ptr(self.dinv), None,
+                float(a.w_off if a.w_off is not None else 1.0), _lib.ptr(a.corr), self.x_row_offset,
                 _lib.ptr(full), full.stride(0), _lib.ptr(out), out.stride(0), epi, _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(dev)))
             return

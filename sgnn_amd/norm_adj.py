@@ -190,8 +190,8 @@ class NormAdj:
 
     def _rowgroup_plan(self, F):
         """Row-group plan for feature width F, or None when the plain CSR kernel
-        must be used (off-diagonal weights differ, unsupported width, switched off)."""
-        if not self.use_rowgroup or self.w_off is None or self.nnz == 0:
+        must be used (unsupported width, switched off)."""
+        if not self.use_rowgroup or self.nnz == 0:
             return None
         lib = _lib.load()
         R = lib.sgnn_rowgroup_config(F)
@@ -210,7 +210,17 @@ class NormAdj:
                 counts = buf[:32].view(torch.int64).cpu()       # synchronises
                 del ws
             merged, items, slots, n_long = (int(v) for v in counts)
-            plan = dict(R=R, buf=buf, bytes=pbytes, merged=merged, items=items, slots=slots, n_long=n_long, ws={})
+            gw = None
+            if self.w_off is None:
+                # stored values differ: the plan also carries the value of every
+                # (merged column, row of the group) pair
+                gbytes = lib.sgnn_rowgroup_weights_bytes(merged, R)
+                gw = torch.empty(gbytes, dtype=torch.uint8, device=self.device)
+                _lib.check(lib.sgnn_rowgroup_weights(
+                    self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), _lib.ptr(self.vals), R,
+                    _lib.ptr(buf), pbytes, merged, _lib.ptr(gw), gbytes, _lib.current_stream(self.device)))
+            plan = dict(R=R, buf=buf, bytes=pbytes, merged=merged, items=items, slots=slots, n_long=n_long, ws={},
+                        gw=gw)
             self._plans[R] = plan
         return plan
 
@@ -233,10 +243,10 @@ class NormAdj:
         if plan is not None:
             ws = self._rowgroup_ws(plan, F)
             _lib.check(lib.sgnn_spmm_rowgroup_f32(
-                self.n, self.n, self.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
+                self.n, self.n, self.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"], _lib.ptr(plan["gw"]),
                 plan["items"], plan["slots"], plan["n_long"],
                 dinv if scale_rows else None, None,
-                float(self.w_off), _lib.ptr(self.corr), 0,
+                float(self.w_off if self.w_off is not None else 1.0), _lib.ptr(self.corr), 0,
                 _lib.ptr(X), ldx, _lib.ptr(Y), ldy, int(epilogue), _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(self.device)))
             return

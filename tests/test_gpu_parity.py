@@ -422,7 +422,7 @@ def test_rowgroup_entry_point_rejects_what_it_cannot_run(dev):
     st = _lib.current_stream(dev)
 
     def call(x_ptr, ldx, dinv_col=None, items=plan["items"], ws_bytes=ws.numel()):
-        return lib.sgnn_spmm_rowgroup_f32(n, n, adj.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
+        return lib.sgnn_spmm_rowgroup_f32(n, n, adj.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"], None,
                                           items, plan["slots"], plan["n_long"], _lib.ptr(adj.dinv), dinv_col,
                                           1.0, None, 0, x_ptr, ldx, _lib.ptr(Y), F, 0, _lib.ptr(ws), ws_bytes, st)
     assert call(X.data_ptr(), F + 4) == 0
