@@ -61,11 +61,21 @@ class _GraphConvBase(nn.Module):
 
 
 class SGConv(_GraphConvBase):
-    """``lin(A_hat^K x)`` — torch_geometric.nn.SGConv as used at model/SGC.py:11."""
+    """``lin(A_hat^K x)`` — torch_geometric.nn.SGConv as used at model/SGC.py:11.
 
-    def __init__(self, in_channels, out_channels, K=1, cached=False, add_self_loops=True, bias=True):
+    With ``cached=False`` (torch_geometric's default, and what model/SGC.py:11 builds) the
+    propagation is redone on every forward.  ``A_hat^K (x W^T) = (A_hat^K x) W^T``, so when
+    the layer narrows the features (602 -> 41 on Reddit) and nothing is cached the linear
+    map is applied first and the K hops run at the output width — the same result to fp32
+    rounding at a fraction of the gather traffic (``reorder=False`` keeps the literal
+    order).  With ``cached=True`` the propagated features are kept at the input width and
+    only the linear map runs per forward, as in torch_geometric."""
+
+    def __init__(self, in_channels, out_channels, K=1, cached=False, add_self_loops=True, bias=True,
+                 reorder=True):
         super().__init__(add_self_loops, cached)
         self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.reorder = reorder
         self.lin = nn.Linear(in_channels, out_channels, bias=bias)
         self._cached_x = None
 
@@ -75,11 +85,14 @@ class SGConv(_GraphConvBase):
 
     def forward(self, x, edge_index, edge_weight=None):
         if self.cached and self._cached_x is not None:
-            h = self._cached_x
-        else:
-            h = propagate(x, self._norm_adj(x, edge_index, edge_weight), self.K)
-            if self.cached:
-                self._cached_x = h.detach()
+            return self.lin(self._cached_x)
+        adj = self._norm_adj(x, edge_index, edge_weight)
+        if not self.cached and self.reorder and self.out_channels < self.in_channels:
+            out = propagate(torch.nn.functional.linear(x, self.lin.weight), adj, self.K)
+            return out if self.lin.bias is None else out + self.lin.bias
+        h = propagate(x, adj, self.K)
+        if self.cached:
+            self._cached_x = h.detach()
         return self.lin(h)
 
 

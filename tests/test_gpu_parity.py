@@ -440,3 +440,32 @@ def test_rowgroup_entry_point_rejects_what_it_cannot_run(dev):
     a = adj.spmm(Xu)
     b = adj.spmm(Xu.contiguous())
     assert torch.equal(a, b)
+
+
+def test_sgconv_reordered_matches_literal_order(dev):
+    """A_hat^K (x W^T) against (A_hat^K x) W^T: outputs and parameter gradients of the two
+    SGConv evaluation orders agree to fp32 rounding; the cached variant too."""
+    from sgnn_amd.nn import SGConv
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    n, Fin, Fout = 1500, 96, 7
+    r, c = symmetric_simple_numpy(n, 12_000, seed=31)
+    ei = torch.from_numpy(np.stack((r, c))).to(dev)
+    x = torch.randn(n, Fin, device=dev)
+    tgt = torch.randn(n, Fout, device=dev)
+    torch.manual_seed(0)
+    a = SGConv(Fin, Fout, K=2, reorder=True).to(dev)
+    b = SGConv(Fin, Fout, K=2, reorder=False).to(dev)
+    cch = SGConv(Fin, Fout, K=2, cached=True).to(dev)
+    for m in (b, cch):
+        m.load_state_dict(a.state_dict())
+    outs, grads = [], []
+    for m in (a, b, cch):
+        out = m(x, ei)
+        ((out - tgt) ** 2).mean().backward()
+        outs.append(out.detach())
+        grads.append((m.lin.weight.grad.clone(), m.lin.bias.grad.clone()))
+    for o in outs[1:]:
+        assert float((o - outs[0]).norm() / outs[0].norm()) <= 1e-5
+    for gw, gb in grads[1:]:
+        assert float((gw - grads[0][0]).norm() / grads[0][0].norm()) <= 1e-5
+        assert float((gb - grads[0][1]).norm() / grads[0][1].norm()) <= 1e-5
