@@ -64,6 +64,19 @@ def test_argument_errors_are_reported_not_crashes():
     rc = lib.sgnn_sample_block_f32(4, 4, None, None, None, 3, None, 0, None, 2, None)
     assert rc == -1 and b"ldo" in lib.sgnn_last_error()
     assert lib.sgnn_sample_block_f32(4, 4, None, None, None, 0, None, 0, None, 0, None) == 0
+    # batch indices / auto-encoder loss / group weights: argument checks come before any launch
+    assert lib.sgnn_batch_indices(5, 6, None, None, None) == -1 and b"b <= n" in lib.sgnn_last_error()
+    assert lib.sgnn_batch_indices(5, 2, None, None, None) == -1 and b"null" in lib.sgnn_last_error()
+    assert lib.sgnn_gae_targets_f32(4, 4, None, None, None, None, None, 3, None, 1.5, None,
+                                    None, None, None, None, None) == -1 and b"mask_rate" in lib.sgnn_last_error()
+    assert lib.sgnn_gae_targets_f32(4, 4, None, None, None, None, None, 0, None, 0.2, None,
+                                    None, None, None, None, None) == 0
+    assert lib.sgnn_gae_loss_grad_f32(3, None, 2, None, None, None, None, None, None, None) == -1
+    assert lib.sgnn_rowgroup_weights_bytes(1000, 16) >= 1000 * 16 * 4
+    assert lib.sgnn_rowgroup_weights_bytes(1000, 5) == 0
+    assert lib.sgnn_rowgroup_weights(4, 4, None, None, None, 16, None, 0, 4, None, 0, None) == -1
+    assert lib.sgnn_rowgroup_config(16) == 0 and lib.sgnn_rowgroup_config(64) == 8
+    assert lib.sgnn_rowgroup_config(602) == 16 and lib.sgnn_rowgroup_config(3703) == 16
 
 
 def test_no_cpu_fallback():
