@@ -164,10 +164,19 @@ class PartitionedAdj:
             rows = torch.arange(splits[rank], splits[rank + 1], dtype=torch.int64)
         elif partition == "degree_cyclic":
             order, max_rows = degree_cyclic_deal(counts, world)
-            k = torch.arange(n, dtype=torch.int64)
+            # Positions inside a rank's block are shuffled (same seed everywhere): left in
+            # degree order, the hubs of every block would be numbered next to each other and
+            # the SpMM, which walks the columns block by block, would meet all hot rows of X
+            # at once instead of a few per block (measured: 12.6 instead of 10.4 ms).
+            gen = torch.Generator().manual_seed(0x5eed)
             pad = torch.empty(n, dtype=torch.int64)
-            pad[order] = (k % world) * max_rows + k // world
-            rows = order[rank::world].clone()
+            rows = None
+            for p in range(world):
+                mine_p = order[p::world]
+                mine_p = mine_p[torch.randperm(mine_p.numel(), generator=gen)]
+                pad[mine_p] = p * max_rows + torch.arange(mine_p.numel(), dtype=torch.int64)
+                if p == rank:
+                    rows = mine_p.clone()
         else:
             raise ValueError(f"unknown partition {partition!r}")
         # in the padded index space a rank's rows are the contiguous range
