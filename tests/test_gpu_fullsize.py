@@ -81,3 +81,31 @@ def test_x_larger_than_4gib(gpu_device, rowgroup):
     Y_ref = adj.spmm(Xc)
     assert float((Y_big - Y_ref).norm() / Y_ref.norm()) <= 1e-6
     assert torch.equal(Y_big, Y_ref)            # same kernel arithmetic, only the addressing differs
+
+
+def test_rowgroup_kernel_reads_x_larger_than_4gib_in_place(gpu_device):
+    """The row-group kernel itself on an operand that spans more than 4 GiB (already
+    scaled and 16-byte aligned, so nothing is staged into a compact copy): same result as
+    on a compact copy of the same rows."""
+    from sgnn_amd import NormAdj, _lib
+    from sgnn_amd.graphgen import rmat_undirected_device
+    dev = gpu_device
+    n, F, ld = 300_000, 96, 4096
+    row, col = rmat_undirected_device(n, 6_000_000, seed=4, device=dev)
+    adj = NormAdj.from_coo(row, col, None, n, dev)
+    big = torch.zeros(n, ld, device=dev)
+    assert big.numel() * 4 > (1 << 32)
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    Xc = torch.randn(n, F, device=dev, generator=g)
+    big[:, 128:128 + F] = Xc
+    view = big[:, 128:128 + F]
+    assert view.data_ptr() % 16 == 0 and adj._rowgroup_plan(F) is not None
+    Y_big = torch.empty(n, F, device=dev)
+    Y_ref = torch.empty(n, F, device=dev)
+    adj._hop(view, ld, Y_big, F, F, True, False, _lib.EPI_SCALE_ROW)
+    adj._hop(Xc, F, Y_ref, F, F, True, False, _lib.EPI_SCALE_ROW)
+    assert torch.equal(Y_big, Y_ref)
+    # and it is the scaled-input product: dinv * (A+I) * X
+    adj.use_rowgroup = False
+    Y_csr = adj.spmm(Xc, scale_rows=True, scale_cols=False)
+    assert float((Y_ref - Y_csr).norm() / Y_csr.norm()) <= TOL
