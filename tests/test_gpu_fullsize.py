@@ -83,7 +83,8 @@ def test_x_larger_than_4gib(gpu_device, rowgroup):
     assert torch.equal(Y_big, Y_ref)            # same kernel arithmetic, only the addressing differs
 
 
-def test_rowgroup_kernel_reads_x_larger_than_4gib_in_place(gpu_device):
+@pytest.mark.parametrize("weighted", [False, True])
+def test_rowgroup_kernel_reads_x_larger_than_4gib_in_place(gpu_device, weighted):
     """The row-group kernel itself on an operand that spans more than 4 GiB (already
     scaled and 16-byte aligned, so nothing is staged into a compact copy): same result as
     on a compact copy of the same rows."""
@@ -92,10 +93,12 @@ def test_rowgroup_kernel_reads_x_larger_than_4gib_in_place(gpu_device):
     dev = gpu_device
     n, F, ld = 300_000, 96, 4096
     row, col = rmat_undirected_device(n, 6_000_000, seed=4, device=dev)
-    adj = NormAdj.from_coo(row, col, None, n, dev)
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    weights = None if not weighted else torch.rand(row.numel(), device=dev, generator=g) + 0.5
+    adj = NormAdj.from_coo(row, col, weights, n, dev)
+    assert (adj.w_off is None) == weighted
     big = torch.zeros(n, ld, device=dev)
     assert big.numel() * 4 > (1 << 32)
-    g = torch.Generator(device=dev); g.manual_seed(6)
     Xc = torch.randn(n, F, device=dev, generator=g)
     big[:, 128:128 + F] = Xc
     view = big[:, 128:128 + F]
