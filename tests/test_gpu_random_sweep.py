@@ -3,6 +3,8 @@ small ragged graphs (empty rows, isolated nodes, duplicates, self-loops, negativ
 fractional weights, n down to 1) under every combination of build flags and self-loop
 modes.  CSR and degrees bit for bit; propagation within 1e-5 (normwise and against
 |A_hat|^k |X| element-wise)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -12,6 +14,7 @@ from golden_util import abs_scale, rel_err, scaled_err
 from oracle import sgnn_oracle as orc
 
 pytestmark = pytest.mark.gpu
+EXTRA = int(os.environ.get("SGNN_SWEEP_EXTRA", "0"))      # more seeds for a soak run
 
 
 def _graph(rng):
@@ -34,7 +37,7 @@ def _graph(rng):
     return n, r.astype(np.int64), c.astype(np.int64), v
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(96 + EXTRA))
 def test_build_flags_and_loop_modes_bit_exact(gpu_device, seed):
     from sgnn_amd.norm_adj import NormAdj
     rng = np.random.default_rng(1000 + seed)
@@ -56,10 +59,17 @@ def test_build_flags_and_loop_modes_bit_exact(gpu_device, seed):
         exp = orc.norm_csr(A.row, A.col, A.data, n, drop_zeros=True)
         adj = NormAdj.from_coo(r, c, v, n, gpu_device, symmetrize=True, clamp_one=True, drop_zeros=True)
         assert np.array_equal(adj.rowptr.cpu().numpy(), exp[0]) and np.array_equal(adj.colidx.cpu().numpy(), exp[1])
-        assert np.array_equal(adj.vals.cpu().numpy(), exp[2]) and np.array_equal(adj.deg.cpu().numpy(), exp[3])
+        if v is None or (v == np.round(v)).all():
+            # the loaders' case: 0/1 (or small integer) entries, every sum exact in fp32
+            assert np.array_equal(adj.vals.cpu().numpy(), exp[2]) and np.array_equal(adj.deg.cpu().numpy(), exp[3])
+        else:
+            # scipy sorts a row's entries with an unstable sort before it sums duplicates, so
+            # three or more fractional duplicates of one entry have no defined summation order
+            np.testing.assert_allclose(adj.vals.cpu().numpy(), exp[2], rtol=3e-7, atol=0)
+            np.testing.assert_allclose(adj.deg.cpu().numpy(), exp[3], rtol=1e-6, atol=0)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(64 + EXTRA))
 def test_propagation_random_graphs_and_widths(gpu_device, seed):
     from sgnn_amd.norm_adj import NormAdj
     rng = np.random.default_rng(2000 + seed)
