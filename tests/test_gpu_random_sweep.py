@@ -91,3 +91,51 @@ def test_propagation_random_graphs_and_widths(gpu_device, seed):
         scale = abs_scale(rowptr, colidx, vals, dinv, dinv, X, order)
         assert rel_err(Y, exp) <= 1e-5, (seed, n, F, order, use_rg)
         assert scaled_err(Y, exp, scale) <= 1e-5, (seed, n, F, order, use_rg)
+
+
+def _clustered_graph(rng):
+    """Heavy-tailed degrees with neighbourhoods concentrated in communities, so that rows of
+    one group share columns (the case the merged column lists and the per-XCD dealing of
+    the row-group kernel are built for), plus a few hubs longer than one segment."""
+    n = int(rng.integers(2000, 40000))
+    size = int(rng.choice([50, 300, 2000]))
+    deg = np.minimum((rng.pareto(1.6, n) * rng.uniform(2, 12)).astype(np.int64) + 1, n // 2)
+    hubs = rng.integers(0, n, 3)
+    deg[hubs] = rng.integers(1500, 6000, 3).clip(max=n - 1)
+    r = np.repeat(np.arange(n), deg)
+    home = (r // size) * size
+    local = home + rng.integers(0, size, r.size)
+    c = np.where(rng.random(r.size) < 0.8, local, rng.integers(0, n, r.size)).clip(max=n - 1)
+    return n, r.astype(np.int64), c.astype(np.int64)
+
+
+@pytest.mark.parametrize("seed", range(20 + EXTRA // 20))
+def test_propagation_clustered_graphs(gpu_device, seed):
+    """Mid-sized graphs through every feature layout of the row-group kernel (16-, 8- and
+    4-byte chunks, sliced widths), uniform and per-entry weights, symmetric or not."""
+    from sgnn_amd.norm_adj import NormAdj
+    rng = np.random.default_rng(3000 + seed)
+    n, r, c = _clustered_graph(rng)
+    F = int(rng.choice([33, 64, 100, 128, 130, 200, 256, 300, 512, 602, 640, 644, 700, 1000, 1433]))
+    F = min(F, max(33, int(4e8 // max(r.size, 1))))         # keeps the float64 oracle to about a second
+    weighted = bool(rng.integers(0, 2))
+    v = (rng.random(r.size).astype(np.float32) + np.float32(0.1)) if weighted else None
+    sym = bool(rng.integers(0, 2))
+    order = int(rng.integers(1, 3))
+    if sym:
+        A = orc.symmetrize_binarize(r, c, None, n).tocoo()
+        r, c, v = A.row.astype(np.int64), A.col.astype(np.int64), None
+    vv = np.ones(r.size, np.float32) if v is None else v
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, vv, n)
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    exp = X
+    for _ in range(order):
+        exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, exp)
+    scale = abs_scale(rowptr, colidx, vals, dinv, dinv, X, order)
+    adj = NormAdj.from_coo(r, c, v, n, gpu_device)
+    assert np.array_equal(adj.rowptr.cpu().numpy(), rowptr) and np.array_equal(adj.colidx.cpu().numpy(), colidx)
+    assert np.array_equal(adj.vals.cpu().numpy(), vals) and np.array_equal(adj.deg.cpu().numpy(), deg)
+    Y = adj.propagate(torch.from_numpy(X).to(gpu_device), order).cpu().numpy()
+    tag = (seed, n, r.size, F, weighted, sym, order)
+    assert rel_err(Y, exp) <= 1e-5, tag
+    assert scaled_err(Y, exp, scale) <= 1e-5, tag
