@@ -79,6 +79,23 @@ def load_traffic(workload):
         return None
 
 
+def copy_ceiling(device, mib=2048, reps=10):
+    """Read + write GB/s of a device-to-device copy of ``mib`` MiB: the streaming rate this
+    card delivers, to set beside the vendor peak."""
+    import torch
+    src = torch.empty(mib << 18, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * src.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +265,7 @@ def main():
         wall = float(t.item())
     ev_ms = ev0.elapsed_time(ev1) / args.steps              # HIP events on the launch stream
 
+    copy_gbps = copy_ceiling(device) if (rank == 0 and world == 1) else None
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         units = nnz * F * args.order                          # (E + n) . F per hop
@@ -289,6 +307,12 @@ def main():
                 "gather_bytes_no_reuse": nnz * F * 4 * args.order,
             },
         }
+        roof = out["roofline"]
+        if copy_gbps:                                         # what a streaming copy reaches on this card
+            roof["copy_ceiling"] = copy_gbps
+            roof["frac_of_copy"] = achieved / copy_gbps
+        if roof["traffic"]:                                   # bytes the L2s fetched or wrote, per launch
+            roof["fabric_GBps"] = roof["traffic"] / (ev_ms * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, F, args.seed, device, args.cpu_sample_edges)
         print(json.dumps(out, ensure_ascii=False), flush=True)
