@@ -291,6 +291,46 @@ int sgnn_gae_targets_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, con
 int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* target, const float* retain,
                            const float* row_pos, const float* row_ret, float* G, float* row_loss, void* stream);
 
+/*
+ * The dense tail of one optimiser iteration of a decoupled layer, one launch each.
+ *
+ * sgnn_adam_step_f32: one Adam update (torch.optim.Adam as model/SGNN.py:417-432 uses it:
+ *   no amsgrad, weight decay added to the gradient) of up to 16 contiguous fp32 tensors:
+ *     g = grad + weight_decay[k] * p + l1_decay[k] * sign(p);  m += (1 - beta1) * (g - m);  v = beta2 * v + (1 - beta2) * g * g;
+ *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = steps so far + 1.
+ *   params / grads / exp_avg / exp_avg_sq / sizes / weight_decay are HOST arrays of `count`
+ *   entries (device pointers, element counts, per-tensor penalties; a NULL penalty array = 0).
+ *   `state` is uint64[2] in device memory, zero before the first step: {steps taken,
+ *   internal}; the launch advances it, so a captured HIP graph keeps counting on replay.
+ *   With weight_decay = 2 * lam on W, b and U this also covers the ridge penalty of
+ *   model/SGNN.py:89-92, with l1_decay = lam the LASSO penalty of model/SGNN.py:93-96
+ *   (their gradients; the penalty's value is not added to any reported loss).
+ * sgnn_softmax_xent_f32: loss[0] = mean_i( logsumexp(z_i) - z_i[y_i] ) and
+ *   dlogits = (softmax(z) - onehot(y)) / B for logits z (B x C, row stride ldz) —
+ *   torch's CrossEntropyLoss with its backward (model/SGNN.py:397-399).
+ *   y_i = labels[idx[i]] when idx (int64[B]) is given, else labels[i]; labels is
+ *   int64[n_labels]; a row whose label is out of range contributes no loss term.
+ * sgnn_sq_err_f32: loss[0] = scale * sum_ij (a_ij - t_ij)^2 and grad = 2 * scale * (a - t)
+ *   for a (B x D, row stride lda) — the embedding-target term eta * ||a - t||_F^2 / B of
+ *   model/SGNN.py:80-86, 393.  Row i of t is target[idx[i]] when idx is given, else
+ *   target[i]; target has target_rows rows of stride ldt.
+ * Both losses take `workspace` (sgnn_loss_workspace_bytes(B) bytes of device memory, contents
+ * irrelevant) and `ticket`, one uint32 in device memory that is ZERO on entry and is left zero
+ * when the launch has finished (the workgroups count themselves in on it; the last one adds
+ * the per-row terms in a fixed order, so the loss value does not depend on scheduling).  Calls
+ * that overlap on different streams need tickets of their own.
+ */
+int sgnn_adam_step_f32(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* sizes, const float* weight_decay,
+                       const float* l1_decay, float lr, float beta1, float beta2, float eps, uint64_t* state, void* stream);
+size_t sgnn_loss_workspace_bytes(int64_t B);
+int sgnn_softmax_xent_f32(int64_t B, int64_t C, const float* logits, int64_t ldz, const int64_t* labels,
+                          int64_t n_labels, const int64_t* idx, float* loss, float* dlogits, int64_t ldd,
+                          void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream);
+int sgnn_sq_err_f32(int64_t B, int64_t D, const float* a, int64_t lda, const float* target, int64_t ldt,
+                    int64_t target_rows, const int64_t* idx, float scale, float* loss, float* grad,
+                    int64_t ldg, void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

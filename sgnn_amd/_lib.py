@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgnn_hip.so")
@@ -61,6 +61,13 @@ SIGNATURES = {
     "sgnn_gae_loss_grad_f32": (c_int, [c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
     "sgnn_batch_indices": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sgnn_adam_step_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_float, c_float, c_float, c_void_p, c_void_p]),
+    "sgnn_loss_workspace_bytes": (c_size_t, [c_int64]),
+    "sgnn_softmax_xent_f32": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "sgnn_sq_err_f32": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_float,
+                                c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "sgnn_sample_block_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                       c_void_p, c_int64, c_void_p]),
 }

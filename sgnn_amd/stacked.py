@@ -94,6 +94,135 @@ def _glorot(rows, cols, device):
     return torch.nn.Parameter((torch.rand(rows, cols, device=device) * 2 - 1) * bound)
 
 
+class _FusedAdam:
+    """``torch.optim.Adam`` (default betas / eps, coupled weight decay per group) for a
+    handful of small tensors as ONE launch per step (``sgnn_adam_step_f32``) instead of a
+    multi-tensor pass per parameter group plus step-counter kernels; a group's ``l1_decay``
+    adds ``l1_decay * sign(p)`` to the gradient (the LASSO penalty).  The step number lives
+    in device memory and is advanced by the kernel, so a captured iteration keeps counting
+    when the HIP graph is replayed.  Parameters whose ``.grad`` is None are skipped, as
+    torch does."""
+    MAX_TENSORS = 16
+
+    def __init__(self, groups, lr, device, betas=(0.9, 0.999), eps=1e-8):
+        self.entries = [(q, float(g.get("weight_decay", 0.0)), float(g.get("l1_decay", 0.0)))
+                        for g in groups for q in g["params"]]
+        for q, _, _ in self.entries:
+            if q.dtype != torch.float32 or not q.is_contiguous():
+                raise ValueError("fused Adam needs contiguous fp32 parameters")
+        self.lr, self.betas, self.eps, self.device = float(lr), betas, float(eps), device
+        self.exp_avg = [torch.zeros_like(e[0]) for e in self.entries]
+        self.exp_avg_sq = [torch.zeros_like(e[0]) for e in self.entries]
+        self.state = torch.zeros(2, dtype=torch.int64, device=device)
+
+    def zero_grad(self, set_to_none=True):
+        for q, _, _ in self.entries:
+            if set_to_none:
+                q.grad = None
+            elif q.grad is not None:
+                q.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        import ctypes
+        live = [k for k, e in enumerate(self.entries) if e[0].grad is not None]
+        if not live:
+            return
+        for k in live:
+            g = self.entries[k][0].grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise ValueError("fused Adam needs contiguous fp32 gradients")
+        n = len(live)
+        ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+        sizes = (ctypes.c_int64 * n)(*[self.entries[k][0].numel() for k in live])
+        decay = (ctypes.c_float * n)(*[self.entries[k][1] for k in live])
+        l1 = (ctypes.c_float * n)(*[self.entries[k][2] for k in live])
+        _lib.check(_lib.load().sgnn_adam_step_f32(
+            n, ptrs([self.entries[k][0] for k in live]), ptrs([self.entries[k][0].grad for k in live]),
+            ptrs([self.exp_avg[k] for k in live]), ptrs([self.exp_avg_sq[k] for k in live]), sizes, decay, l1,
+            self.lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(self.state), _lib.current_stream(self.device)))
+
+
+_TICKETS = {}
+
+
+def _ticket(device):
+    """The zero-initialised counter the fused loss kernels count their workgroups in on
+    (they leave it zero); one per device, since the layers train on one stream."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _TICKETS:
+        _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _TICKETS[key]
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    """Mean cross-entropy of ``logits`` against ``labels[idx]`` and its gradient in one
+    launch (``sgnn_softmax_xent_f32``)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, idx):
+        logits = logits.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dz = torch.empty_like(logits)
+        B, C = logits.shape
+        ws = torch.empty(B, dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.load().sgnn_softmax_xent_f32(B, C, _lib.ptr(logits), C, _lib.ptr(labels), labels.numel(),
+                                                     _lib.ptr(idx) if idx is not None else None, _lib.ptr(loss),
+                                                     _lib.ptr(dz), C, _lib.ptr(ws), ws.numel() * 4,
+                                                     _lib.ptr(_ticket(logits.device)),
+                                                     _lib.current_stream(logits.device)))
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (dz,) = ctx.saved_tensors
+        return dz * grad_loss, None, None
+
+
+class _SqErr(torch.autograd.Function):
+    """``scale * ||a - target[idx]||_F^2`` and its gradient in one launch (``sgnn_sq_err_f32``)."""
+
+    @staticmethod
+    def forward(ctx, a, target, idx, scale):
+        a = a.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        grad = torch.empty_like(a)
+        B, D = a.shape
+        ws = torch.empty(B, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().sgnn_sq_err_f32(B, D, _lib.ptr(a), D, _lib.ptr(target), target.stride(0),
+                                               target.shape[0], _lib.ptr(idx) if idx is not None else None,
+                                               float(scale), _lib.ptr(loss), _lib.ptr(grad), D, _lib.ptr(ws),
+                                               ws.numel() * 4, _lib.ptr(_ticket(a.device)),
+                                               _lib.current_stream(a.device)))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_loss, None, None, None
+
+
+_FUSED_LOSS_MAX = 1 << 30      # elements
+
+
+def _cross_entropy(logits, labels, idx):
+    """``cross_entropy(logits, labels[idx])`` (mean over rows)."""
+    if (logits.is_cuda and logits.dtype == torch.float32 and labels.dtype == torch.int64 and labels.is_contiguous()
+            and 0 < logits.numel() <= _FUSED_LOSS_MAX):
+        return _SoftmaxXent.apply(logits, labels, idx)
+    return Fn.cross_entropy(logits, labels[idx])
+
+
+def _squared_error(a, target, idx, scale):
+    """``scale * ((a - target[idx]) ** 2).sum()``."""
+    if (a.is_cuda and a.dtype == torch.float32 and target.dtype == torch.float32 and target.dim() == 2
+            and target.stride(1) == 1 and 0 < a.numel() <= _FUSED_LOSS_MAX):
+        return _SqErr.apply(a, target, idx, scale)
+    return scale * (a - target[idx]).pow(2).sum()
+
+
 class _Layer(torch.nn.Module):
     """What every decoupled layer shares (SingleLayerGNN, model/SGNN.py:18-117)."""
 
@@ -110,18 +239,25 @@ class _Layer(torch.nn.Module):
         self.b = _glorot(1, embedding_dim, device)
         self.U = torch.nn.Parameter(torch.eye(input_dim, device=device), requires_grad=False)
         self.expected_X = None
+        self._u_identity = True          # U still holds the identity it was created with / reset to
         self.use_graph = p.get("use_graph", True)
         self._rng_state = None
         self._cache_in, self._cache_version, self._cache_val = None, -1, None
 
     def set_training_direction(self, is_backward, reset_backward=True):
         self.U.requires_grad = is_backward
-        if not is_backward and reset_backward:
+        if is_backward:
+            self._u_identity = False     # about to be trained
+        elif reset_backward:
             with torch.no_grad():
                 self.U.copy_(torch.eye(self.U.shape[0], device=self.device))
+            self._u_identity = True
 
     def forward(self, X):
-        return self.activation(self.inner_activation(X.matmul(self.U)).matmul(self.W))
+        # X . I = X exactly in fp32 (x * 1 plus exact zeros), so the product is skipped
+        # while U is the untrained identity: forward sweeps and plain stacked training
+        XU = X if self._u_identity else X.matmul(self.U)
+        return self.activation(self.inner_activation(XU).matmul(self.W))
 
     def propagated(self, X):
         """``A_hat^order X``, recomputed only when the input changes."""
@@ -155,24 +291,34 @@ class _Layer(torch.nn.Module):
     # 0.7-1.2 ms, nearly all of it launch overhead on the host.
     GRAPH_WARMUP = 3
 
-    def _optimise(self, loss_fn, ridge=0.0):
+    def _optimise(self, loss_fn, ridge=0.0, lasso=0.0):
         """``max_iter`` Adam steps on ``loss_fn()`` with a fresh optimiser (model/SGNN.py:417).
 
         ``ridge`` > 0 adds the penalty ``ridge * (|W|^2 + |b|^2 + |U|^2)`` of
         model/SGNN.py:88-92 through its gradient ``2 * ridge * p``, which is what Adam's
         (coupled) ``weight_decay`` adds to the gradient: the same update without the six
-        reduction kernels and their backward per iteration."""
+        reduction kernels and their backward per iteration.  ``lasso`` > 0 adds
+        ``lasso * (|W|_1 + |b|_1 + |U|_1)`` (model/SGNN.py:93-96) the same way, as
+        ``lasso * sign(p)`` on the gradient inside the fused update."""
         use_graph = self.use_graph and self.device.type == "cuda" and self.max_iter > 2 * self.GRAPH_WARMUP
         penalised = [self.W, self.b, self.U]
         others = [q for q in self.parameters() if all(q is not t for t in penalised)]
         groups = [dict(params=penalised, weight_decay=2.0 * ridge)]
         if others:
             groups.append(dict(params=others, weight_decay=0.0))
-        opt = torch.optim.Adam(groups, lr=self.lr, capturable=use_graph,
-                               fused=True if self.device.type == "cuda" else None)
+        lasso_in_loss = 0.0
+        if self.device.type == "cuda" and sum(len(g["params"]) for g in groups) <= _FusedAdam.MAX_TENSORS:
+            groups[0]["l1_decay"] = lasso
+            opt = _FusedAdam(groups, self.lr, self.device)
+        else:
+            lasso_in_loss = lasso
+            opt = torch.optim.Adam(groups, lr=self.lr, capturable=use_graph,
+                                   fused=True if self.device.type == "cuda" else None)
 
         def step():
             loss = loss_fn()
+            if lasso_in_loss:
+                loss = loss + lasso_in_loss * self._lasso()
             loss.backward()
             opt.step()
 
@@ -196,8 +342,7 @@ class _Layer(torch.nn.Module):
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                step()
-            done += 1
+                step()                           # recorded, not run
         except RuntimeError as exc:
             # an activation or loss the caller plugged in may not be capturable; the
             # iterations are then issued one by one (same arithmetic, more launch overhead)
@@ -215,7 +360,7 @@ class _Layer(torch.nn.Module):
     def _finish(self, X, PX):
         with torch.no_grad():
             embedding = self(PX)
-            self.expected_X = X.matmul(self.U)
+            self.expected_X = X if self._u_identity else X.matmul(self.U)
         return embedding
 
 
@@ -238,13 +383,13 @@ class EmbeddingLayer(_Layer):
                 idx = self._batch(tX.shape[0])
                 emb = self(tX[idx])
                 if tT is None:
-                    loss = Fn.cross_entropy(emb.matmul(self.Wt), tY[idx])
+                    loss = _cross_entropy(emb.matmul(self.Wt), tY, idx)
                 else:
-                    loss = eta * (emb - tT[idx]).pow(2).sum() / emb.shape[0]
+                    loss = _squared_error(emb, tT, idx, eta / emb.shape[0])
                 if embedding_target is not None:
                     jdx = self._batch(PX.shape[0])
                     e2 = self(PX[jdx])
-                    loss = loss + eta * (e2 - embedding_target[jdx]).pow(2).sum() / e2.shape[0]
+                    loss = loss + _squared_error(e2, embedding_target, jdx, eta / e2.shape[0])
                 return loss
 
             self._optimise(loss_fn, ridge=self.lam)
@@ -339,12 +484,11 @@ class GAELayer(_Layer):
                 else:
                     target = self.adjacency.sample_block(idx, skip_self=True)          # model/SGNN.py:167-170
                     loss = self.reconstruction_loss(self.decode(emb), target, 1 - self._ignore_mask(idx))
-                loss = loss + self.lam * self._lasso()
                 if embedding_target is not None:
-                    loss = loss + eta * (emb - embedding_target[idx]).pow(2).sum() / emb.shape[0]
+                    loss = loss + _squared_error(emb, embedding_target, idx, eta / emb.shape[0])
                 return loss
 
-            self._optimise(loss_fn)
+            self._optimise(loss_fn, lasso=self.lam)                                    # model/SGNN.py:162
         return self._finish(X, PX)
 
 

@@ -1,0 +1,158 @@
+"""The fused pieces of an optimiser iteration (Adam update, label-head cross-entropy,
+embedding-target squared error) against the stock torch operators they replace."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(dev, seed):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    shapes = [(602, 128), (1, 128), (602, 602), (128, 41), (3,), (1025,)]
+    return [torch.nn.Parameter(torch.randn(*s, device=dev, generator=g) * 0.1) for s in shapes], g
+
+
+@pytest.mark.parametrize("l1", [0.0, 1e-3])
+def test_fused_adam_follows_torch_adam(gpu_device, l1):
+    from sgnn_amd.stacked import _FusedAdam
+    mine, g = _params(gpu_device, 1)
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    split = 3
+    fused = _FusedAdam([dict(params=mine[:split], weight_decay=2e-3, l1_decay=l1),
+                        dict(params=mine[split:], weight_decay=0.0)], 1e-2, gpu_device)
+    stock = torch.optim.Adam([dict(params=ref[:split], weight_decay=2e-3),
+                              dict(params=ref[split:], weight_decay=0.0)], lr=1e-2)
+    for it in range(40):
+        for k, (a, b) in enumerate(zip(mine, ref)):
+            if k == 4 and it % 2:                    # a parameter without a gradient is left alone
+                a.grad = b.grad = None
+                continue
+            grad = torch.randn(a.shape, device=gpu_device, generator=g)
+            a.grad = grad.clone()
+            b.grad = grad.clone() + (l1 * torch.sign(b.detach()) if k < split else 0)
+        fused.step()
+        stock.step()
+    assert int(fused.state[0].item()) == 40 and int(fused.state[1].item()) == 0
+    for a, b in zip(mine, ref):
+        if a.shape == (3,):
+            continue                                  # stepped on its own schedule above: torch keeps a per-tensor count
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_fused_adam_counts_steps_under_graph_replay(gpu_device):
+    from sgnn_amd.stacked import _FusedAdam
+    p = torch.nn.Parameter(torch.ones(5000, device=gpu_device))
+    q = torch.nn.Parameter(torch.ones(5000, device=gpu_device))
+    p.grad = torch.full_like(p, 0.5)
+    q.grad = torch.full_like(q, 0.5)
+    fused = _FusedAdam([dict(params=[p])], 1e-2, gpu_device)
+    stock = torch.optim.Adam([q], lr=1e-2)
+    side = torch.cuda.Stream(gpu_device)
+    side.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(side):
+        fused.step()
+    torch.cuda.current_stream(gpu_device).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fused.step()
+    for _ in range(9):                                           # capturing records the step without running it
+        graph.replay()
+    for _ in range(10):
+        stock.step()
+    torch.cuda.synchronize()
+    assert int(fused.state[0].item()) == 10
+    np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("B,C", [(1, 1), (17, 41), (512, 41), (512, 64), (300, 65), (64, 200), (20000, 41)])
+@pytest.mark.parametrize("indexed", [False, True])
+def test_softmax_xent_matches_torch(gpu_device, B, C, indexed):
+    from sgnn_amd.stacked import _cross_entropy
+    g = torch.Generator(device=gpu_device); g.manual_seed(B * 1000 + C)
+    z = (torch.randn(B, C, device=gpu_device, generator=g) * 4).requires_grad_()
+    z2 = z.detach().clone().requires_grad_()
+    n_lab = 3 * B if indexed else B
+    labels = torch.randint(0, C, (n_lab,), device=gpu_device, generator=g)
+    idx = torch.randperm(n_lab, device=gpu_device, generator=g)[:B] if indexed else None
+    mine = _cross_entropy(z, labels, idx)
+    ref = Fn.cross_entropy(z2, labels[idx] if indexed else labels)
+    (3.0 * mine).backward()
+    (3.0 * ref).backward()
+    assert abs(mine.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    np.testing.assert_allclose(z.grad.cpu().numpy(), z2.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("B,D", [(1, 1), (512, 128), (512, 64), (100, 130), (30001, 64)])
+@pytest.mark.parametrize("indexed", [False, True])
+def test_squared_error_matches_torch(gpu_device, B, D, indexed):
+    from sgnn_amd.stacked import _squared_error
+    g = torch.Generator(device=gpu_device); g.manual_seed(B + D)
+    a = torch.randn(B, D, device=gpu_device, generator=g).requires_grad_()
+    a2 = a.detach().clone().requires_grad_()
+    rows = 4 * B if indexed else B
+    wide = torch.randn(rows, D + 6, device=gpu_device, generator=g)
+    target = wide[:, 3:3 + D]                                   # strided rows
+    idx = torch.randint(0, rows, (B,), device=gpu_device, generator=g) if indexed else None
+    scale = 1000.0 / B
+    mine = _squared_error(a, target, idx, scale)
+    ref = scale * (a2 - (target[idx] if indexed else target)).pow(2).sum()
+    (0.5 * mine).backward()
+    (0.5 * ref).backward()
+    assert abs(mine.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    np.testing.assert_allclose(a.grad.cpu().numpy(), a2.grad.cpu().numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_identity_projection_is_skipped_exactly(gpu_device):
+    from sgnn_amd.stacked import EmbeddingLayer, LayerParam, get_activation
+    from sgnn_amd.norm_adj import NormAdj
+    n, F = 300, 70
+    rng = np.random.default_rng(0)
+    r, c = rng.integers(0, n, 2000), rng.integers(0, n, 2000)
+    adj = NormAdj.from_coo(r, c, None, n, gpu_device)
+    p = LayerParam(16, inner_act=get_activation("leaky_relu=0.2"), act=get_activation("linear"))
+    layer = EmbeddingLayer(adj, torch.zeros(n, dtype=torch.long, device=gpu_device),
+                           torch.ones(n, dtype=torch.bool, device=gpu_device), F, 16, 2, p, gpu_device)
+    X = torch.randn(n, F, device=gpu_device)
+    assert layer._u_identity
+    skipped = layer(X)
+    layer._u_identity = False
+    assert torch.equal(skipped, layer(X))
+    layer.set_training_direction(True)
+    assert not layer._u_identity
+    layer.set_training_direction(False)                          # resets U to the identity
+    assert layer._u_identity and torch.equal(layer.U, torch.eye(F, device=gpu_device))
+
+
+def test_train_step_entry_points_reject_bad_arguments(gpu_device):
+    from sgnn_amd import _lib
+    lib = _lib.load()
+    state = torch.zeros(2, dtype=torch.int64, device=gpu_device)
+    st = _lib.current_stream(gpu_device)
+    arr = (ctypes.c_void_p * 17)()
+    sizes = (ctypes.c_int64 * 17)()
+    assert lib.sgnn_adam_step_f32(17, arr, arr, arr, arr, sizes, None, None, 1e-3, 0.9, 0.999, 1e-8,
+                                  _lib.ptr(state), st) != 0
+    assert lib.sgnn_adam_step_f32(1, arr, arr, arr, arr, sizes, None, None, 1e-3, 1.0, 0.999, 1e-8,
+                                  _lib.ptr(state), st) != 0
+    assert lib.sgnn_adam_step_f32(0, None, None, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8,
+                                  _lib.ptr(state), st) == 0          # nothing to do
+    z = torch.zeros(4, 4, device=gpu_device)
+    lab = torch.zeros(4, dtype=torch.int64, device=gpu_device)
+    loss = torch.zeros((), device=gpu_device)
+    ws = torch.zeros(4, device=gpu_device)
+    tick = torch.zeros(1, dtype=torch.int32, device=gpu_device)
+    w = (_lib.ptr(ws), 16, _lib.ptr(tick), st)
+    assert lib.sgnn_loss_workspace_bytes(4) == 16
+    assert lib.sgnn_softmax_xent_f32(4, 4, _lib.ptr(z), 3, _lib.ptr(lab), 4, None, _lib.ptr(loss), _lib.ptr(z), 4, *w) != 0
+    assert lib.sgnn_softmax_xent_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(lab), 3, None, _lib.ptr(loss), _lib.ptr(z), 4, *w) != 0
+    assert lib.sgnn_softmax_xent_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(lab), 4, None, _lib.ptr(loss), _lib.ptr(z), 4,
+                                     _lib.ptr(ws), 12, _lib.ptr(tick), st) != 0            # workspace too small
+    assert lib.sgnn_sq_err_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(z), 4, 3, None, 1.0, _lib.ptr(loss), _lib.ptr(z), 4, *w) != 0
+    assert lib.sgnn_sq_err_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(z), 4, 4, None, 1.0, _lib.ptr(loss), _lib.ptr(z), 4,
+                               _lib.ptr(ws), 16, None, st) != 0                             # no ticket
+    torch.cuda.synchronize()
+    assert int(state[0].item()) == 0 and int(tick.item()) == 0
