@@ -254,10 +254,10 @@ int sgnn_sample_block_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, co
 /*
  * out[0:b] = the first b entries of a pseudo-random permutation of [0, n): distinct
  * int64 node ids, as torch.randperm(n)[:b] gives the layers per optimiser iteration
- * (model/SGNN.py:115-117), without sorting n keys.  `state` is uint64[2] in device
- * memory, {seed, counter}; the call uses and then increments the counter on the
- * stream, so a captured HIP graph that contains it draws a new batch on every
- * replay.  The permutation is a 4-round Feistel network with cycle walking: a
+ * (model/SGNN.py:115-117), without sorting n keys.  `state` is uint64[3] in device
+ * memory, {seed, counter, 0}; the third word is internal, zero on entry and left zero.
+ * The call uses and then increments the counter on the stream, so a captured HIP graph
+ * that contains it draws a new batch on every replay.  The permutation is a 4-round Feistel network with cycle walking: a
  * bijection for every (seed, counter), not a cryptographic one.
  */
 int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t* out, void* stream);
@@ -272,7 +272,7 @@ int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t* out, void
  *   retain = 1 - max(random symmetric ignore mask without diagonal, overlook block)
  *            (model/SGNN.py:157-159, 172-175, 209-226): a pair is ignored with
  *            probability 2*mask_rate - mask_rate^2 (either of the reference's two draws),
- *            drawn from `state` = uint64[2] {seed, counter} (counter advanced on the
+ *            drawn from `state` = uint64[3] {seed, counter, 0} (counter advanced on the
  *            stream, as in sgnn_batch_indices); the overlook matrix is its unit diagonal
  *            plus, optionally, the pattern of a second CSR (overlook_rowptr/colidx, sorted
  *            columns; both NULL = diagonal only),
@@ -296,7 +296,8 @@ int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* 
  *
  * sgnn_adam_step_f32: one Adam update (torch.optim.Adam as model/SGNN.py:417-432 uses it:
  *   no amsgrad, weight decay added to the gradient) of up to 16 contiguous fp32 tensors:
- *     g = grad + weight_decay[k] * p + l1_decay[k] * sign(p);  m += (1 - beta1) * (g - m);  v = beta2 * v + (1 - beta2) * g * g;
+ *     g = grad + weight_decay[k] * p + l1_decay[k] * sign(p);
+ *     m += (1 - beta1) * (g - m);  v = beta2 * v + (1 - beta2) * g * g;
  *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = steps so far + 1.
  *   params / grads / exp_avg / exp_avg_sq / sizes / weight_decay are HOST arrays of `count`
  *   entries (device pointers, element counts, per-tensor penalties; a NULL penalty array = 0).
@@ -315,21 +316,41 @@ int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* 
  *   model/SGNN.py:80-86, 393.  Row i of t is target[idx[i]] when idx is given, else
  *   target[i]; target has target_rows rows of stride ldt.
  * Both losses take `workspace` (sgnn_loss_workspace_bytes(B) bytes of device memory, contents
- * irrelevant) and `ticket`, one uint32 in device memory that is ZERO on entry and is left zero
- * when the launch has finished (the workgroups count themselves in on it; the last one adds
- * the per-row terms in a fixed order, so the loss value does not depend on scheduling).  Calls
- * that overlap on different streams need tickets of their own.
+ * irrelevant): the per-row terms go through it and are added in a fixed order by a second
+ * small launch, so the loss value does not depend on scheduling.
  */
 int sgnn_adam_step_f32(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* sizes, const float* weight_decay,
-                       const float* l1_decay, float lr, float beta1, float beta2, float eps, uint64_t* state, void* stream);
+                       const float* l1_decay, float lr, float beta1, float beta2, float eps, uint64_t* state,
+                       void* stream);
 size_t sgnn_loss_workspace_bytes(int64_t B);
 int sgnn_softmax_xent_f32(int64_t B, int64_t C, const float* logits, int64_t ldz, const int64_t* labels,
                           int64_t n_labels, const int64_t* idx, float* loss, float* dlogits, int64_t ldd,
-                          void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream);
+                          void* workspace, size_t workspace_bytes, void* stream);
 int sgnn_sq_err_f32(int64_t B, int64_t D, const float* a, int64_t lda, const float* target, int64_t ldt,
                     int64_t target_rows, const int64_t* idx, float scale, float* loss, float* grad,
-                    int64_t ldg, void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream);
+                    int64_t ldg, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * A layer's projection of one batch with the row gather and the inner activation folded
+ * into the operand load (model/SGNN.py:73-78 applied to the rows model/SGNN.py:106-121
+ * picked, while the layer's U is the identity):
+ *   sgnn_batch_project_f32      E  (b x N) = act(X[idx]) . W        W  is F x N, row stride ldw
+ *   sgnn_batch_project_grad_f32 dW (F x N) = act(X[idx])^T . dE     dE is b x N, row stride ldde
+ * act(x) = x > 0 ? x : slope * x (slope 1 = linear, 0 = relu, else leaky_relu); X has n_rows
+ * rows of F floats with row stride ldx; idx is int64[b], an id outside [0, n_rows) reads as
+ * a zero row.  fp32 throughout, fused multiply-adds in a fixed order: the reduction
+ * dimension is cut into chunks handled by different workgroups whose partial tiles go through
+ * `workspace` (sgnn_batch_project_workspace_bytes bytes, contents irrelevant; `grad` selects
+ * which of the two calls the size is for) and are added in chunk order by a second launch.
+ */
+size_t sgnn_batch_project_workspace_bytes(int64_t b, int64_t F, int64_t N, int grad);
+int sgnn_batch_project_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b, const int64_t* idx,
+                           float slope, const float* W, int64_t ldw, int64_t N, float* E, int64_t lde,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int sgnn_batch_project_grad_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b,
+                                const int64_t* idx, float slope, const float* dE, int64_t ldde, int64_t N,
+                                float* dW, int64_t lddw, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,8 +63,11 @@ extern "C" int sgnn_sample_block_f32(int64_t n_rows, int64_t nnz, const int32_t*
 // the iteration.  Here the permutation is a keyed bijection — a 4-round Feistel
 // network on 2*h bits (2^(2h) >= n) with cycle walking back into [0, n) — evaluated
 // only at positions 0..b-1, so the indices are distinct by construction.  The key is
-// (seed, counter) in device memory; the kernel advances the counter, so replaying a
-// captured HIP graph draws a new batch every time.
+// (seed, counter) in device memory; the launch advances the counter, so replaying a
+// captured HIP graph draws a new batch every time.  state[2] counts the workgroups that
+// have finished: each reads the key before it counts itself in, and the last one advances
+// the counter, so no workgroup of a launch sees the key change under it (nothing else
+// passes between workgroups, so no fence is involved).
 namespace {
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // murmur3 finaliser
@@ -72,7 +75,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // murmur3 finaliser
   return x;
 }
 
-__global__ __launch_bounds__(256) void k_batch_indices(int64_t n, int64_t b, uint64_t* __restrict__ state,
+__global__ __launch_bounds__(256) void k_batch_indices(int64_t n, int64_t b, unsigned long long* state,
                                                        int64_t* __restrict__ out) {
   const uint64_t seed = state[0], counter = state[1];
   int h = 1;
@@ -97,9 +100,15 @@ __global__ __launch_bounds__(256) void k_batch_indices(int64_t n, int64_t b, uin
     } while (int64_t(x) >= n);
     out[i] = int64_t(x);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long done = atomicAdd(&state[2], 1ull);
+    if (done == gridDim.x - 1ull) {
+      state[2] = 0ull;
+      state[1] = counter + 1ull;
+    }
+  }
 }
-
-__global__ void k_batch_advance(uint64_t* state) { state[1] += 1; }
 
 }  // namespace
 
@@ -109,12 +118,9 @@ extern "C" int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t
   if (n > (int64_t(1) << 62)) return fail(SGNN_ERR_INVALID, "n too large");
   if (!state || (b > 0 && !out)) return fail(SGNN_ERR_INVALID, "null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (b > 0) {
-    const unsigned blocks = unsigned(b < 65536 * 256 ? (b + 255) / 256 : 65536);
-    hipLaunchKernelGGL(k_batch_indices, dim3(blocks), dim3(256), 0, st, n, b, state, out);
-    HIP_TRY(hipGetLastError());
-  }
-  hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(1), 0, st, state);
+  const unsigned blocks = unsigned(b < 65536 * 256 ? (b + 255) / 256 : 65536);
+  hipLaunchKernelGGL(k_batch_indices, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, n, b,
+                     reinterpret_cast<unsigned long long*>(state), out);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
                                                      const int* __restrict__ colidx, const float* __restrict__ vals,
                                                      const int* __restrict__ o_rowptr, const int* __restrict__ o_colidx,
                                                      int64_t b, const int64_t* __restrict__ idx, float p_mask,
-                                                     const uint64_t* __restrict__ state, float* __restrict__ target,
+                                                     unsigned long long* state, float* __restrict__ target,
                                                      float* __restrict__ retain, float* __restrict__ row_pos,
                                                      float* __restrict__ row_ret) {
   const int64_t i = blockIdx.x;
@@ -165,8 +171,9 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
   const bool ok = node >= 0 && node < n_rows;
   const int lo0 = ok ? rowptr[node] : 0, hi0 = ok ? rowptr[node + 1] : 0;
   const int olo = (ok && o_rowptr) ? o_rowptr[node] : 0, ohi = (ok && o_rowptr) ? o_rowptr[node + 1] : 0;
-  const uint32_t k0 = mix32(uint32_t(state[0]) ^ mix32(uint32_t(state[1]) + 0x9e3779b9u));
-  const uint32_t k1 = mix32(uint32_t(state[0] >> 32) + mix32(uint32_t(state[1] >> 32) ^ 0x85ebca6bu));
+  const uint64_t seed = state[0], counter = state[1];
+  const uint32_t k0 = mix32(uint32_t(seed) ^ mix32(uint32_t(counter) + 0x9e3779b9u));
+  const uint32_t k1 = mix32(uint32_t(seed >> 32) + mix32(uint32_t(counter >> 32) ^ 0x85ebca6bu));
   const uint32_t thresh = p_mask >= 1.f ? 0xffffffffu : uint32_t(double(p_mask) * 4294967296.0);
   float s_pos = 0.f, s_ret = 0.f;
   for (int64_t j = threadIdx.x; j < b; j += blockDim.x) {
@@ -200,6 +207,12 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
   if (threadIdx.x == 0) {
     row_pos[i] = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
     row_ret[i] = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+    // the last workgroup to finish advances the counter (see k_batch_indices)
+    const unsigned long long done = atomicAdd(&state[2], 1ull);
+    if (done == gridDim.x - 1ull) {
+      state[2] = 0ull;
+      state[1] = counter + 1ull;
+    }
   }
 }
 
@@ -263,9 +276,8 @@ extern "C" int sgnn_gae_targets_f32(int64_t n_rows, int64_t nnz, const int32_t* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float p = 2.f * mask_rate - mask_rate * mask_rate;   // either of the two draws masks the pair
   hipLaunchKernelGGL(k_gae_targets, dim3(unsigned(b)), dim3(256), 0, st, n_rows, rowptr, colidx, vals, overlook_rowptr,
-                     overlook_colidx, b, idx, p, state, target, retain, row_pos, row_ret);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(1), 0, st, state);
+                     overlook_colidx, b, idx, p, reinterpret_cast<unsigned long long*>(state), target, retain, row_pos,
+                     row_ret);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }

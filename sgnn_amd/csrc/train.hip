@@ -7,8 +7,8 @@
 // plus its step bookkeeping).  Here each is one launch.
 //
 // Sums are formed in a fixed order (per row by one wavefront whose lanes fold in halves,
-// then over the rows by the last workgroup to finish), so a loss value does not depend on
-// scheduling.
+// then over the rows by one wavefront in a launch of its own), so a loss value does not
+// depend on scheduling.
 #include "common.h"
 
 namespace {
@@ -75,13 +75,11 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a, float lr, float beta1,
     s_v[k][j] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
+  if (threadIdx.x == 0) {       // no data passes between workgroups, so the count needs no fence
     const unsigned long long done = atomicAdd(&state[1], 1ull);
     if (done == gridDim.x - 1ull) {
       state[1] = 0ull;
       state[0] = step;
-      __threadfence();
     }
   }
 }
@@ -100,35 +98,24 @@ __device__ __forceinline__ float wave_sum(float x) {
 constexpr int kLossWaves = 4;                    // rows per workgroup: one wavefront each
 constexpr int kLossThreads = kLossWaves * 64;
 
-// Adds row_loss[0..B) in a fixed order (lane l takes l, l + 64, ..., then the lanes fold in
-// halves) once every workgroup of the launch has written its rows.  `ticket` counts the
-// finished workgroups; the last one sums, stores and puts the ticket back to zero.
-__device__ __forceinline__ void finish_loss(int64_t B, const float* row_loss, unsigned int* ticket, float factor,
-                                            float* loss) {
-  __shared__ bool last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
-    __threadfence();
-  }
-  __syncthreads();
-  if (!last || threadIdx.x >= 64) return;
+// loss[0] = factor * (row_loss[0] + ... + row_loss[B-1]) in a fixed order: lane l takes
+// l, l + 64, ..., then the lanes fold in halves.  A launch of its own, so that the rows
+// written by the workgroups of the previous launch are visible without a device-wide fence
+// (which costs more than a launch when hundreds of workgroups issue it).
+__global__ __launch_bounds__(64) void k_sum_rows(int64_t B, const float* __restrict__ row_loss, float factor,
+                                                 float* __restrict__ loss) {
   float t = 0.f;
-  for (int64_t r = threadIdx.x; r < B; r += 64) t += __builtin_nontemporal_load(row_loss + r);
+  for (int64_t r = threadIdx.x; r < B; r += 64) t += row_loss[r];
   t = wave_sum(t);
-  if (threadIdx.x == 0) {
-    loss[0] = t * factor;
-    *ticket = 0u;
-  }
+  if (threadIdx.x == 0) loss[0] = t * factor;
 }
 
 // One wavefront per row; its lanes stride over the classes.
 __global__ __launch_bounds__(kLossThreads) void k_softmax_xent(int64_t B, int64_t C, const float* __restrict__ z,
                                                                int64_t ldz, const int64_t* __restrict__ labels,
                                                                const int64_t* __restrict__ idx, int64_t n_labels,
-                                                               float* loss, float* __restrict__ dz, int64_t ldd,
-                                                               float* row_loss, unsigned int* ticket) {
+                                                               float* __restrict__ dz, int64_t ldd,
+                                                               float* __restrict__ row_loss) {
   const int lane = threadIdx.x & 63;
   const int64_t r = int64_t(blockIdx.x) * kLossWaves + (threadIdx.x >> 6);
   const float inv_b = 1.f / float(B);
@@ -147,15 +134,14 @@ __global__ __launch_bounds__(kLossThreads) void k_softmax_xent(int64_t B, int64_
       dz[r * ldd + c] = (expf(zr[c] - mx) * inv_s - (c == y ? 1.f : 0.f)) * inv_b;
     if (lane == 0) row_loss[r] = (y >= 0 && y < C) ? mx + logf(s) - zr[y] : 0.f;
   }
-  finish_loss(B, row_loss, ticket, inv_b, loss);
 }
 
 // loss = scale * sum (a - t)^2, grad = 2 * scale * (a - t); t's rows optionally picked by idx.
 __global__ __launch_bounds__(kLossThreads) void k_sq_err(int64_t B, int64_t D, const float* __restrict__ a,
                                                          int64_t lda, const float* __restrict__ t, int64_t ldt,
                                                          const int64_t* __restrict__ idx, int64_t t_rows, float scale,
-                                                         float* loss, float* __restrict__ grad, int64_t ldg,
-                                                         float* row_loss, unsigned int* ticket) {
+                                                         float* __restrict__ grad, int64_t ldg,
+                                                         float* __restrict__ row_loss) {
   const int lane = threadIdx.x & 63;
   const int64_t r = int64_t(blockIdx.x) * kLossWaves + (threadIdx.x >> 6);
   if (r < B) {
@@ -171,7 +157,125 @@ __global__ __launch_bounds__(kLossThreads) void k_sq_err(int64_t B, int64_t D, c
     acc = wave_sum(acc);
     if (lane == 0) row_loss[r] = acc;
   }
-  finish_loss(B, row_loss, ticket, scale, loss);
+}
+
+
+// ---------------------------------------------------------------------------------
+// The layer's projection of one batch, E = act(X[idx]) . W, and its weight gradient
+// dW = act(X[idx])^T . dE, with the row gather and the inner activation
+// act(x) = x > 0 ? x : slope * x applied while the operand is loaded
+// (model/SGNN.py:73-78 on the rows get_samples picked, :106-121, while U is the identity).
+// The products are 512 x 602 x 128-sized: far too small to fill the chip, so what counts is
+// latency.  A stock library call picks a large macro-tile (8 workgroups busy, ~19 us) after
+// separate gather and activation launches; here one launch covers all three with 32 x 32
+// output tiles, operands staged through LDS and the next K-slab prefetched into registers
+// while the current one is multiplied.
+constexpr int kT = 64;                            // output tile edge
+constexpr int kChunk = 32;                        // reduction depth handled by one workgroup
+
+// The reduction dimension is cut into chunks of 32 handled by different workgroups
+// (blockIdx.z), so a 512 x 602 x 128 product runs as ~300 short workgroups instead of a few
+// long ones whose every K-slab costs a global-memory round trip.  Each thread forms a 4 x 4
+// block of its workgroup's 64 x 64 partial tile; k_project_sum then adds the partial tiles in
+// chunk order (a launch of its own rather than a device-wide fence inside this one).
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_batch_project(int64_t n_rows, int64_t F, const float* __restrict__ X,
+                                                       int64_t ldx, int64_t b, const int64_t* __restrict__ idx,
+                                                       float slope, const float* __restrict__ Bm, int64_t ldb,
+                                                       int64_t N, float* __restrict__ C, int64_t ldc,
+                                                       float4* __restrict__ partial) {
+  // forward: C[b x N] = A . Bm,  A(m, k) = act(X[idx[m]][k]),  M = b, K = F,  Bm = W  (F x N)
+  // GRAD   : C[F x N] = A . Bm,  A(m, k) = act(X[idx[k]][m]),  M = F, K = b,  Bm = dE (b x N)
+  __shared__ __align__(16) float As[kChunk][kT + 4];   // As[k][m]
+  __shared__ __align__(16) float Bs[kChunk][kT + 4];   // Bs[k][n]
+  const int64_t M = GRAD ? F : b, K = GRAD ? b : F;
+  const int64_t m0 = int64_t(blockIdx.y) * kT, n0 = int64_t(blockIdx.x) * kT;
+  const int64_t k0 = int64_t(blockIdx.z) * kChunk;
+  const int t = threadIdx.x;
+  if (!GRAD) {                                    // row t / 4 of the tile, 8 consecutive k
+    const int lm = t >> 2, lk = (t & 3) * 8;
+    const int64_t m = m0 + lm;
+    int64_t r = m < b ? idx[m] : -1;
+    if (r >= n_rows) r = -1;
+    const float* src = X + r * ldx + k0 + lk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (r >= 0 && k0 + lk + e < K) ? src[e] : 0.f;
+      As[lk + e][lm] = x > 0.f ? x : slope * x;
+    }
+  } else {                                        // batch position t / 8 of the chunk, 8 consecutive features
+    const int lk = t >> 3, lm = (t & 7) * 8;
+    const int64_t k = k0 + lk;
+    int64_t r = k < K ? idx[k] : -1;
+    if (r >= n_rows) r = -1;
+    const float* src = X + r * ldx + m0 + lm;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (r >= 0 && m0 + lm + e < M) ? src[e] : 0.f;
+      As[lk][lm + e] = x > 0.f ? x : slope * x;
+    }
+  }
+  {
+    const int lk = t >> 3, ln = (t & 7) * 8;
+    const int64_t k = k0 + lk;
+    const float* src = Bm + k * ldb + n0 + ln;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Bs[lk][ln + e] = (k < K && n0 + ln + e < N) ? src[e] : 0.f;
+  }
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;             // 4 x 4 outputs at (4 ty, 4 tx)
+  float c[4][4] = {};
+#pragma unroll
+  for (int k = 0; k < kChunk; ++k) {
+    const float4 av = *reinterpret_cast<const float4*>(&As[k][4 * ty]);
+    const float4 bv = *reinterpret_cast<const float4*>(&Bs[k][4 * tx]);
+    const float a[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[i][j] = fmaf(a[i], bb[j], c[i][j]);
+  }
+  if (gridDim.z > 1) {
+    const int64_t tile = int64_t(blockIdx.y) * gridDim.x + blockIdx.x, tiles = int64_t(gridDim.x) * gridDim.y;
+    float4* mine = partial + (int64_t(blockIdx.z) * tiles + tile) * 1024 + t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mine[i * 256] = make_float4(c[i][0], c[i][1], c[i][2], c[i][3]);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + 4 * ty + i;
+    if (m >= M) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + 4 * tx + j;
+      if (n < N) C[m * ldc + n] = c[i][j];
+    }
+  }
+}
+
+// C tile = sum over the chunks of the partial tiles, in chunk order.  Same thread-to-output
+// mapping as k_batch_project: thread t holds rows 4 (t / 16) + i, columns 4 (t % 16) ..; one
+// workgroup per (tile, i), so every thread adds one float4 per chunk.
+__global__ __launch_bounds__(256) void k_project_sum(int64_t M, int64_t N, int splits,
+                                                     const float4* __restrict__ partial, float* __restrict__ C,
+                                                     int64_t ldc) {
+  const int64_t tile = int64_t(blockIdx.y) * gridDim.x + blockIdx.x, tiles = int64_t(gridDim.x) * gridDim.y;
+  const int t = threadIdx.x, ty = t >> 4, tx = t & 15, i = blockIdx.z;
+  const float4* src = partial + tile * 1024 + i * 256 + t;
+  const int64_t stride = tiles * 1024;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int z = 0; z < splits; ++z) {
+    const float4 v = src[z * stride];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const int64_t m = int64_t(blockIdx.y) * kT + 4 * ty + i, n = int64_t(blockIdx.x) * kT + 4 * tx;
+  if (m >= M) return;
+  if (n < N) C[m * ldc + n] = acc.x;
+  if (n + 1 < N) C[m * ldc + n + 1] = acc.y;
+  if (n + 2 < N) C[m * ldc + n + 2] = acc.z;
+  if (n + 3 < N) C[m * ldc + n + 3] = acc.w;
 }
 
 }  // namespace
@@ -213,10 +317,10 @@ extern "C" size_t sgnn_loss_workspace_bytes(int64_t B) {
 }
 
 namespace {
-int check_loss_ws(int64_t B, const void* ws, size_t ws_bytes, const void* ticket) {
+int check_loss_ws(int64_t B, const void* ws, size_t ws_bytes) {
   using sgnn::fail;
   if (B > 0x7fffffff) return fail(SGNN_ERR_INVALID, "more than 2^31-1 rows");
-  if (!ticket || (B > 0 && !ws)) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (B > 0 && !ws) return fail(SGNN_ERR_INVALID, "null pointer");
   if (ws_bytes < sgnn_loss_workspace_bytes(B)) return fail(SGNN_ERR_WORKSPACE, "loss workspace too small");
   return SGNN_OK;
 }
@@ -224,32 +328,109 @@ int check_loss_ws(int64_t B, const void* ws, size_t ws_bytes, const void* ticket
 
 extern "C" int sgnn_softmax_xent_f32(int64_t B, int64_t C, const float* logits, int64_t ldz, const int64_t* labels,
                                      int64_t n_labels, const int64_t* idx, float* loss, float* dlogits, int64_t ldd,
-                                     void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream) {
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   using sgnn::fail;
   if (B <= 0 || C <= 0) return fail(SGNN_ERR_INVALID, "need B > 0 and C > 0");
   if (ldz < C || ldd < C) return fail(SGNN_ERR_INVALID, "row stride smaller than the class count");
   if (n_labels < 0 || (!idx && n_labels < B)) return fail(SGNN_ERR_INVALID, "fewer labels than rows");
   if (!logits || !labels || !loss || !dlogits) return fail(SGNN_ERR_INVALID, "null pointer");
-  if (int rc = check_loss_ws(B, workspace, workspace_bytes, ticket)) return rc;
+  if (int rc = check_loss_ws(B, workspace, workspace_bytes)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* rows = static_cast<float*>(workspace);
   const unsigned blocks = unsigned((B + kLossWaves - 1) / kLossWaves);
-  hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream), B, C,
-                     logits, ldz, labels, idx, n_labels, loss, dlogits, ldd, static_cast<float*>(workspace), ticket);
+  hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(kLossThreads), 0, st, B, C, logits, ldz, labels, idx, n_labels,
+                     dlogits, ldd, rows);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(64), 0, st, B, rows, 1.f / float(B), loss);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
 
 extern "C" int sgnn_sq_err_f32(int64_t B, int64_t D, const float* a, int64_t lda, const float* target, int64_t ldt,
                                int64_t target_rows, const int64_t* idx, float scale, float* loss, float* grad,
-                               int64_t ldg, void* workspace, size_t workspace_bytes, uint32_t* ticket, void* stream) {
+                               int64_t ldg, void* workspace, size_t workspace_bytes, void* stream) {
   using sgnn::fail;
   if (B <= 0 || D <= 0 || target_rows < 0) return fail(SGNN_ERR_INVALID, "need B > 0, D > 0");
   if (lda < D || ldt < D || ldg < D) return fail(SGNN_ERR_INVALID, "row stride smaller than the width");
   if (!idx && target_rows < B) return fail(SGNN_ERR_INVALID, "fewer target rows than rows");
   if (!loss || !a || !target || !grad) return fail(SGNN_ERR_INVALID, "null pointer");
-  if (int rc = check_loss_ws(B, workspace, workspace_bytes, ticket)) return rc;
+  if (int rc = check_loss_ws(B, workspace, workspace_bytes)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* rows = static_cast<float*>(workspace);
   const unsigned blocks = unsigned((B + kLossWaves - 1) / kLossWaves);
-  hipLaunchKernelGGL(k_sq_err, dim3(blocks), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream), B, D, a, lda,
-                     target, ldt, idx, target_rows, scale, loss, grad, ldg, static_cast<float*>(workspace), ticket);
+  hipLaunchKernelGGL(k_sq_err, dim3(blocks), dim3(kLossThreads), 0, st, B, D, a, lda, target, ldt, idx, target_rows,
+                     scale, grad, ldg, rows);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(64), 0, st, B, rows, scale, loss);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
+}
+
+namespace {
+struct ProjectGrid { int64_t tiles_n, tiles_m, splits; };
+ProjectGrid project_grid(int64_t M, int64_t N, int64_t K) {
+  return {(N + kT - 1) / kT, (M + kT - 1) / kT, (K + kChunk - 1) / kChunk};
+}
+int check_project(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b, const int64_t* idx, int64_t N) {
+  using sgnn::fail;
+  if (n_rows < 0 || F <= 0 || b <= 0 || N <= 0) return fail(SGNN_ERR_INVALID, "need F > 0, b > 0, N > 0");
+  if (ldx < F) return fail(SGNN_ERR_INVALID, "ldx smaller than the feature width");
+  if (!X || !idx) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (b > 65535 * int64_t(kT) || F > 65535 * int64_t(kT) || N > (int64_t(1) << 20) * kT)
+    return fail(SGNN_ERR_INVALID, "dimension too large for one launch");
+  return SGNN_OK;
+}
+template <bool GRAD>
+int launch_project(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b, const int64_t* idx, float slope,
+                   const float* Bm, int64_t ldb, int64_t N, float* C, int64_t ldc, void* ws, size_t ws_bytes,
+                   void* stream) {
+  using sgnn::fail;
+  const ProjectGrid g = GRAD ? project_grid(F, N, b) : project_grid(b, N, F);
+  if (g.splits > 1) {
+    if (ws_bytes < size_t(g.splits * g.tiles_m * g.tiles_n) * 1024 * sizeof(float4))
+      return fail(SGNN_ERR_WORKSPACE, "projection workspace too small");
+    if (!ws) return fail(SGNN_ERR_INVALID, "null pointer");
+    if (g.splits > 65535) return fail(SGNN_ERR_INVALID, "dimension too large for one launch");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(unsigned(g.tiles_n), unsigned(g.tiles_m), unsigned(g.splits));
+  hipLaunchKernelGGL(k_batch_project<GRAD>, grid, dim3(256), 0, st, n_rows, F, X, ldx, b, idx, slope, Bm, ldb, N, C,
+                     ldc, static_cast<float4*>(ws));
+  HIP_TRY(hipGetLastError());
+  if (g.splits > 1) {
+    hipLaunchKernelGGL(k_project_sum, dim3(unsigned(g.tiles_n), unsigned(g.tiles_m), 4), dim3(256), 0, st, GRAD ? F : b, N,
+                       int(g.splits), static_cast<const float4*>(ws), C, ldc);
+    HIP_TRY(hipGetLastError());
+  }
+  return SGNN_OK;
+}
+}  // namespace
+
+extern "C" size_t sgnn_batch_project_workspace_bytes(int64_t b, int64_t F, int64_t N, int grad) {
+  if (b <= 0 || F <= 0 || N <= 0) return 0;
+  const ProjectGrid g = grad ? project_grid(F, N, b) : project_grid(b, N, F);
+  return g.splits > 1 ? size_t(g.splits * g.tiles_m * g.tiles_n) * 1024 * sizeof(float4) : 0;
+}
+
+extern "C" int sgnn_batch_project_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b,
+                                      const int64_t* idx, float slope, const float* W, int64_t ldw, int64_t N, float* E,
+                                      int64_t lde, void* workspace, size_t workspace_bytes, void* stream) {
+  using sgnn::fail;
+  if (int rc = check_project(n_rows, F, X, ldx, b, idx, N)) return rc;
+  if (ldw < N || lde < N) return fail(SGNN_ERR_INVALID, "row stride smaller than the output width");
+  if (!W || !E) return fail(SGNN_ERR_INVALID, "null pointer");
+  return launch_project<false>(n_rows, F, X, ldx, b, idx, slope, W, ldw, N, E, lde, workspace, workspace_bytes,
+                               stream);
+}
+
+extern "C" int sgnn_batch_project_grad_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b,
+                                           const int64_t* idx, float slope, const float* dE, int64_t ldde, int64_t N,
+                                           float* dW, int64_t lddw, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+  using sgnn::fail;
+  if (int rc = check_project(n_rows, F, X, ldx, b, idx, N)) return rc;
+  if (ldde < N || lddw < N) return fail(SGNN_ERR_INVALID, "row stride smaller than the output width");
+  if (!dE || !dW) return fail(SGNN_ERR_INVALID, "null pointer");
+  return launch_project<true>(n_rows, F, X, ldx, b, idx, slope, dE, ldde, N, dW, lddw, workspace, workspace_bytes,
+                              stream);
 }

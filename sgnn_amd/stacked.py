@@ -143,16 +143,50 @@ class _FusedAdam:
             self.lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(self.state), _lib.current_stream(self.device)))
 
 
-_TICKETS = {}
+class _BatchProject(torch.autograd.Function):
+    """``act(X[idx]) @ W`` with the gather and the inner activation folded into the operand
+    load (``sgnn_batch_project_f32``); the backward forms ``dW`` the same way.  ``X`` is data
+    (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, X, idx, W, slope):
+        b, (F, N) = idx.numel(), W.shape
+        E = torch.empty(b, N, dtype=torch.float32, device=X.device)
+        lib = _lib.load()
+        ws = torch.empty(lib.sgnn_batch_project_workspace_bytes(b, F, N, 0) // 4, dtype=torch.float32, device=X.device)
+        _lib.check(lib.sgnn_batch_project_f32(X.shape[0], F, _lib.ptr(X), X.stride(0), b, _lib.ptr(idx),
+                                              float(slope), _lib.ptr(W), W.stride(0), N, _lib.ptr(E), N,
+                                              _lib.ptr(ws), ws.numel() * 4, _lib.current_stream(X.device)))
+        ctx.save_for_backward(X, idx)
+        ctx.slope, ctx.shape = float(slope), (F, N)
+        return E
+
+    @staticmethod
+    def backward(ctx, dE):
+        X, idx = ctx.saved_tensors
+        F, N = ctx.shape
+        dE = dE.contiguous()
+        dW = torch.empty(F, N, dtype=torch.float32, device=X.device)
+        lib, b = _lib.load(), idx.numel()
+        ws = torch.empty(lib.sgnn_batch_project_workspace_bytes(b, F, N, 1) // 4, dtype=torch.float32, device=X.device)
+        _lib.check(lib.sgnn_batch_project_grad_f32(X.shape[0], F, _lib.ptr(X), X.stride(0), b, _lib.ptr(idx),
+                                                   ctx.slope, _lib.ptr(dE), N, N, _lib.ptr(dW), N, _lib.ptr(ws),
+                                                   ws.numel() * 4, _lib.current_stream(X.device)))
+        return None, None, dW, None
 
 
-def _ticket(device):
-    """The zero-initialised counter the fused loss kernels count their workgroups in on
-    (they leave it zero); one per device, since the layers train on one stream."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    if key not in _TICKETS:
-        _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _TICKETS[key]
+def _activation_slope(act):
+    """The slope s of ``act(x) = x if x > 0 else s * x`` for the activations that have that
+    form (linear, relu, leaky_relu), else None."""
+    if not isinstance(act, Func):
+        return None
+    if act.func is None:
+        return 1.0
+    if act.func is Fn.relu and not act.params:
+        return 0.0
+    if act.func is Fn.leaky_relu and set(act.params) <= {"negative_slope"}:
+        return float(act.params.get("negative_slope", 0.01))
+    return None
 
 
 class _SoftmaxXent(torch.autograd.Function):
@@ -169,7 +203,6 @@ class _SoftmaxXent(torch.autograd.Function):
         _lib.check(_lib.load().sgnn_softmax_xent_f32(B, C, _lib.ptr(logits), C, _lib.ptr(labels), labels.numel(),
                                                      _lib.ptr(idx) if idx is not None else None, _lib.ptr(loss),
                                                      _lib.ptr(dz), C, _lib.ptr(ws), ws.numel() * 4,
-                                                     _lib.ptr(_ticket(logits.device)),
                                                      _lib.current_stream(logits.device)))
         ctx.save_for_backward(dz)
         return loss
@@ -193,8 +226,7 @@ class _SqErr(torch.autograd.Function):
         _lib.check(_lib.load().sgnn_sq_err_f32(B, D, _lib.ptr(a), D, _lib.ptr(target), target.stride(0),
                                                target.shape[0], _lib.ptr(idx) if idx is not None else None,
                                                float(scale), _lib.ptr(loss), _lib.ptr(grad), D, _lib.ptr(ws),
-                                               ws.numel() * 4, _lib.ptr(_ticket(a.device)),
-                                               _lib.current_stream(a.device)))
+                                               ws.numel() * 4, _lib.current_stream(a.device)))
         ctx.save_for_backward(grad)
         return loss
 
@@ -259,6 +291,19 @@ class _Layer(torch.nn.Module):
         XU = X if self._u_identity else X.matmul(self.U)
         return self.activation(self.inner_activation(XU).matmul(self.W))
 
+    def embed_batch(self, X, idx):
+        """``self(X[idx])``; one launch for gather, inner activation and projection while U
+        is the identity and the inner activation is linear / relu / leaky_relu."""
+        slope = _activation_slope(self.inner_activation)
+        if (self._u_identity and slope is not None and X.is_cuda and X.dtype == torch.float32 and X.dim() == 2
+                and X.stride(1) == 1 and not X.requires_grad and self.W.is_contiguous() and idx.numel() > 0):
+            return self.activation(_BatchProject.apply(X, idx, self.W, slope))
+        if (not self._u_identity and X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1
+                and not X.requires_grad and self.U.is_contiguous() and idx.numel() > 0):
+            XU = _BatchProject.apply(X, idx, self.U, 1.0)          # gather folded into X[idx] . U and into dU
+            return self.activation(self.inner_activation(XU).matmul(self.W))
+        return self(X[idx])
+
     def propagated(self, X):
         """``A_hat^order X``, recomputed only when the input changes."""
         # keyed on the tensor object (kept alive here, so its storage cannot be reused
@@ -279,7 +324,7 @@ class _Layer(torch.nn.Module):
         sort of ``rows`` keys, and it draws afresh on every replay of a HIP graph."""
         if self._rng_state is None:      # seeded from torch's generator, so torch.manual_seed governs it
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            self._rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+            self._rng_state = torch.tensor([seed, 0, 0], dtype=torch.int64, device=self.device)
         b = min(self.batch_size, rows)
         out = torch.empty(b, dtype=torch.int64, device=self.device)
         _lib.check(_lib.load().sgnn_batch_indices(rows, b, _lib.ptr(self._rng_state), _lib.ptr(out),
@@ -381,14 +426,14 @@ class EmbeddingLayer(_Layer):
 
             def loss_fn():
                 idx = self._batch(tX.shape[0])
-                emb = self(tX[idx])
+                emb = self.embed_batch(tX, idx)
                 if tT is None:
                     loss = _cross_entropy(emb.matmul(self.Wt), tY, idx)
                 else:
                     loss = _squared_error(emb, tT, idx, eta / emb.shape[0])
                 if embedding_target is not None:
                     jdx = self._batch(PX.shape[0])
-                    e2 = self(PX[jdx])
+                    e2 = self.embed_batch(PX, jdx)
                     loss = loss + _squared_error(e2, embedding_target, jdx, eta / e2.shape[0])
                 return loss
 
@@ -477,7 +522,7 @@ class GAELayer(_Layer):
         if train:
             def loss_fn():
                 idx = self._batch(PX.shape[0])
-                emb = self(PX[idx])
+                emb = self.embed_batch(PX, idx)
                 if self.fused_loss:
                     loss = _FusedReconstruction.apply(emb, self.adjacency, self.overlook, idx, self.mask_rate,
                                                       self._rng_state)[0]

@@ -116,7 +116,7 @@ def test_fused_reconstruction_matches_autograd(gpu_device):
         gen = torch.Generator().manual_seed(b)
         idx = torch.randperm(n, generator=gen)[:b].to(gpu_device)
         Z = (torch.randn(b, d, generator=gen) * (3.0 if b == 256 else 0.7)).to(gpu_device).requires_grad_(True)
-        state = torch.tensor([99, 5], dtype=torch.int64, device=gpu_device)
+        state = torch.tensor([99, 5, 0], dtype=torch.int64, device=gpu_device)
         loss, target, retain = _FusedReconstruction.apply(Z, adj, overlook, idx, rate, state)
         loss.backward()
         got_grad = Z.grad.clone()
@@ -143,8 +143,8 @@ def test_fused_reconstruction_matches_autograd(gpu_device):
         err = (got_grad - Z2.grad).norm() / Z2.grad.norm().clamp_min(1e-12)
         assert float(err) <= 1e-5, float(err)
     # same (seed, counter) -> same mask; next counter -> another one
-    s1 = torch.tensor([1, 0], dtype=torch.int64, device=gpu_device)
-    s2 = torch.tensor([1, 0], dtype=torch.int64, device=gpu_device)
+    s1 = torch.tensor([1, 0, 0], dtype=torch.int64, device=gpu_device)
+    s2 = torch.tensor([1, 0, 0], dtype=torch.int64, device=gpu_device)
     Z = torch.randn(128, 8, device=gpu_device)
     idx = torch.arange(128, device=gpu_device)
     r1 = _FusedReconstruction.apply(Z, adj, None, idx, 0.3, s1)[2]

@@ -126,18 +126,18 @@ def test_batch_indices_are_a_permutation_head(gpu_device):
         return out.cpu().numpy()
 
     for n in (1, 2, 5, 64, 1000, 4097, 232_965):
-        state = torch.tensor([12345 + n, 0], dtype=torch.int64, device=gpu_device)
+        state = torch.tensor([12345 + n, 0, 0], dtype=torch.int64, device=gpu_device)
         full = draw(n, n, state)
         assert np.array_equal(np.sort(full), np.arange(n)), n
         assert int(state[1]) == 1
         again = draw(n, n, state)
         if n > 64:
             assert not np.array_equal(full, again)
-        state2 = torch.tensor([12345 + n, 0], dtype=torch.int64, device=gpu_device)
+        state2 = torch.tensor([12345 + n, 0, 0], dtype=torch.int64, device=gpu_device)
         assert np.array_equal(draw(n, min(n, 17), state2), full[:min(n, 17)])
     # uniformity: 2000 batches of 512 from 10 000 ids, every id expected 102.4 times
     n, b, reps = 10_000, 512, 2000
-    state = torch.tensor([7, 0], dtype=torch.int64, device=gpu_device)
+    state = torch.tensor([7, 0, 0], dtype=torch.int64, device=gpu_device)
     counts = np.zeros(n, np.int64)
     first = np.zeros(n, np.int64)
     for _ in range(reps):

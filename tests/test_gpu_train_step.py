@@ -144,15 +144,60 @@ def test_train_step_entry_points_reject_bad_arguments(gpu_device):
     lab = torch.zeros(4, dtype=torch.int64, device=gpu_device)
     loss = torch.zeros((), device=gpu_device)
     ws = torch.zeros(4, device=gpu_device)
-    tick = torch.zeros(1, dtype=torch.int32, device=gpu_device)
-    w = (_lib.ptr(ws), 16, _lib.ptr(tick), st)
+    w = (_lib.ptr(ws), 16, st)
     assert lib.sgnn_loss_workspace_bytes(4) == 16
     assert lib.sgnn_softmax_xent_f32(4, 4, _lib.ptr(z), 3, _lib.ptr(lab), 4, None, _lib.ptr(loss), _lib.ptr(z), 4, *w) != 0
     assert lib.sgnn_softmax_xent_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(lab), 3, None, _lib.ptr(loss), _lib.ptr(z), 4, *w) != 0
     assert lib.sgnn_softmax_xent_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(lab), 4, None, _lib.ptr(loss), _lib.ptr(z), 4,
-                                     _lib.ptr(ws), 12, _lib.ptr(tick), st) != 0            # workspace too small
+                                     _lib.ptr(ws), 12, st) != 0                            # workspace too small
     assert lib.sgnn_sq_err_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(z), 4, 3, None, 1.0, _lib.ptr(loss), _lib.ptr(z), 4, *w) != 0
     assert lib.sgnn_sq_err_f32(4, 4, _lib.ptr(z), 4, _lib.ptr(z), 4, 4, None, 1.0, _lib.ptr(loss), _lib.ptr(z), 4,
-                               _lib.ptr(ws), 16, None, st) != 0                             # no ticket
+                               None, 16, st) != 0                                           # no workspace
+    assert lib.sgnn_batch_project_workspace_bytes(512, 602, 128, 0) == 19 * 8 * 2 * 16384
+    assert lib.sgnn_batch_project_f32(8, 64, _lib.ptr(z), 64, 4, _lib.ptr(lab), 0.2, _lib.ptr(z), 4, 4, _lib.ptr(z), 4,
+                                      None, 0, st) != 0                                     # two chunks, no workspace
     torch.cuda.synchronize()
-    assert int(state[0].item()) == 0 and int(tick.item()) == 0
+    assert int(state[0].item()) == 0
+
+
+@pytest.mark.parametrize("b,F,N", [(512, 602, 128), (512, 128, 64), (1, 1, 1), (33, 65, 31), (100, 40, 200)])
+@pytest.mark.parametrize("slope", [1.0, 0.0, 0.2])
+def test_batch_projection_matches_torch(gpu_device, b, F, N, slope):
+    from sgnn_amd.stacked import _BatchProject
+    g = torch.Generator(device=gpu_device); g.manual_seed(b + F + N)
+    n = 3 * b + 5
+    wide = torch.randn(n, F + 3, device=gpu_device, generator=g)
+    X = wide[:, 1:1 + F]                                          # strided rows
+    idx = torch.randint(0, n, (b,), device=gpu_device, generator=g)
+    W = (torch.randn(F, N, device=gpu_device, generator=g) * 0.1).requires_grad_()
+    W2 = W.detach().clone().requires_grad_()
+    dE = torch.randn(b, N, device=gpu_device, generator=g)
+    E = _BatchProject.apply(X, idx, W, slope)
+    ref = Fn.leaky_relu(X[idx].double(), slope).matmul(W2.double())
+    E.backward(dE)
+    ref.backward(dE.double())
+    scale = (Fn.leaky_relu(X[idx].double(), slope).abs().matmul(W2.detach().double().abs())).clamp_min(1e-30)
+    assert ((E.double() - ref).abs() / scale).max().item() <= 1e-5
+    gscale = (Fn.leaky_relu(X[idx].double(), slope).abs().t().matmul(dE.double().abs())).clamp_min(1e-30)
+    assert ((W.grad.double() - W2.grad.double()).abs() / gscale).max().item() <= 1e-5
+
+
+def test_embed_batch_equals_the_unfused_layer(gpu_device):
+    from sgnn_amd.norm_adj import NormAdj
+    from sgnn_amd.stacked import EmbeddingLayer, LayerParam, get_activation
+    n, F = 400, 70
+    rng = np.random.default_rng(0)
+    adj = NormAdj.from_coo(rng.integers(0, n, 2000), rng.integers(0, n, 2000), None, n, gpu_device)
+    for inner, outer in (("leaky_relu=0.2", "linear"), ("relu", "tanh"), ("tanh", "linear")):
+        p = LayerParam(16, inner_act=get_activation(inner), act=get_activation(outer))
+        layer = EmbeddingLayer(adj, torch.zeros(n, dtype=torch.long, device=gpu_device),
+                               torch.ones(n, dtype=torch.bool, device=gpu_device), F, 16, 2, p, gpu_device)
+        X = torch.randn(n, F, device=gpu_device)
+        idx = torch.randperm(n, device=gpu_device)[:64]
+        fused = layer.embed_batch(X, idx)
+        plain = layer(X[idx])
+        np.testing.assert_allclose(fused.detach().cpu().numpy(), plain.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+        fused.sum().backward()
+        g1 = layer.W.grad.clone(); layer.W.grad = None
+        plain.sum().backward()
+        np.testing.assert_allclose(g1.cpu().numpy(), layer.W.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
