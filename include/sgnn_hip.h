@@ -323,6 +323,9 @@ int sgnn_adam_step_f32(int count, float* const* params, const float* const* grad
                        float* const* exp_avg_sq, const int64_t* sizes, const float* weight_decay,
                        const float* l1_decay, float lr, float beta1, float beta2, float eps, uint64_t* state,
                        void* stream);
+/* out[0] = factor * (x[0] + ... + x[n-1]), one wavefront, fixed order (lane l adds l, l + 64, ...,
+ * then the lanes fold in halves): the per-row loss terms of a batch into the scalar loss. */
+int sgnn_sum_f32(int64_t n, const float* x, float factor, float* out, void* stream);
 size_t sgnn_loss_workspace_bytes(int64_t B);
 int sgnn_softmax_xent_f32(int64_t B, int64_t C, const float* logits, int64_t ldz, const int64_t* labels,
                           int64_t n_labels, const int64_t* idx, float* loss, float* dlogits, int64_t ldd,

@@ -159,6 +159,50 @@ __device__ __forceinline__ float csr_lookup(const int* __restrict__ colidx, cons
   return 0.f;
 }
 
+constexpr int kStageCols = 6144, kStageOverlook = 2048;      // 32 KB of LDS per workgroup
+
+// piv[p] = src[p * stride] for p < n, by the whole workgroup, eight loads in flight per thread
+// (issued one at a time, each would cost a trip to HBM: the rows are cold).
+__device__ __forceinline__ void stage_pivots(int* piv, int n, const int* __restrict__ src, int stride) {
+  for (int base = threadIdx.x; base < n; base += 8 * blockDim.x) {
+    int v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = base + e * blockDim.x;
+      v[e] = p < n ? src[int64_t(p) * stride] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = base + e * blockDim.x;
+      if (p < n) piv[p] = v[e];
+    }
+  }
+}
+
+// Position in colidx[lo0, hi0) (ascending) of `want`, or -1.  piv[p] = colidx[lo0 + p * stride]
+// for p < n_piv sits in LDS: the search runs over the pivots first and finishes inside one
+// stride of the global list (stride 1: the whole list is staged and no global step is left).
+__device__ __forceinline__ int staged_find(const int* piv, int n_piv, int stride, const int* __restrict__ colidx,
+                                           int lo0, int hi0, int64_t want) {
+  int lo = 0, hi = n_piv;                         // first pivot > want
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (int64_t(piv[mid]) <= want) lo = mid + 1; else hi = mid;
+  }
+  if (lo == 0) return -1;                         // smaller than the first entry (or empty row)
+  const int p = lo - 1;
+  if (int64_t(piv[p]) == want) return lo0 + p * stride;
+  if (stride == 1) return -1;
+  int a = lo0 + p * stride + 1, b = lo0 + (p + 1) * stride < hi0 ? lo0 + (p + 1) * stride : hi0;
+  while (a < b) {
+    const int mid = a + ((b - a) >> 1);
+    const int64_t c = colidx[mid];
+    if (c == want) return mid;
+    if (c < want) a = mid + 1; else b = mid;
+  }
+  return -1;
+}
+
 __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* __restrict__ rowptr,
                                                      const int* __restrict__ colidx, const float* __restrict__ vals,
                                                      const int* __restrict__ o_rowptr, const int* __restrict__ o_colidx,
@@ -171,6 +215,19 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
   const bool ok = node >= 0 && node < n_rows;
   const int lo0 = ok ? rowptr[node] : 0, hi0 = ok ? rowptr[node + 1] : 0;
   const int olo = (ok && o_rowptr) ? o_rowptr[node] : 0, ohi = (ok && o_rowptr) ? o_rowptr[node + 1] : 0;
+  // The b binary searches of this row all walk the same column list: stage it in LDS with one
+  // coalesced pass, so a search step costs an LDS read instead of a dependent global load.
+  // Of a row longer than the buffer every stride-th entry is staged; the search then ends
+  // with a few global steps inside one stride (a hub row of 10^5 entries: 5 instead of 17).
+  __shared__ int s_cols[kStageCols];
+  __shared__ int s_ocols[kStageOverlook];
+  const int len = hi0 - lo0, olen = ohi - olo;
+  const int stride = (len + kStageCols - 1) / kStageCols > 1 ? (len + kStageCols - 1) / kStageCols : 1;
+  const int ostride = (olen + kStageOverlook - 1) / kStageOverlook > 1 ? (olen + kStageOverlook - 1) / kStageOverlook : 1;
+  const int n_piv = (len + stride - 1) / stride, n_opiv = (olen + ostride - 1) / ostride;
+  stage_pivots(s_cols, n_piv, colidx + lo0, stride);
+  stage_pivots(s_ocols, n_opiv, o_colidx + olo, ostride);
+  __syncthreads();
   const uint64_t seed = state[0], counter = state[1];
   const uint32_t k0 = mix32(uint32_t(seed) ^ mix32(uint32_t(counter) + 0x9e3779b9u));
   const uint32_t k1 = mix32(uint32_t(seed >> 32) + mix32(uint32_t(counter >> 32) ^ 0x85ebca6bu));
@@ -179,13 +236,17 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
   for (int64_t j = threadIdx.x; j < b; j += blockDim.x) {
     const int64_t want = idx[j];
     const bool self = want == node;
-    const float a = self ? 0.f : csr_lookup(colidx, vals, lo0, hi0, want);
+    float a = 0.f;
+    if (!self) {
+      const int pos = staged_find(s_cols, n_piv, stride, colidx, lo0, hi0, want);
+      if (pos >= 0) a = vals ? vals[pos] : 1.f;
+    }
     // one uniform per unordered pair of batch positions
     const uint32_t lo_ij = uint32_t(i < j ? i : j), hi_ij = uint32_t(i < j ? j : i);
     const uint32_t u = mix32(mix32(lo_ij ^ k0) + hi_ij * 0x9e3779b9u + k1);
     bool ignore = (i != j) && (p_mask > 0.f) && (u < thresh || p_mask >= 1.f);
     if (self) ignore = true;                                            // the overlook matrix has a unit diagonal
-    else if (o_rowptr && csr_lookup(o_colidx, nullptr, olo, ohi, want) != 0.f) ignore = true;
+    else if (o_rowptr && staged_find(s_ocols, n_opiv, ostride, o_colidx, olo, ohi, want) >= 0) ignore = true;
     const float r = ignore ? 0.f : 1.f;
     target[i * b + j] = a;
     retain[i * b + j] = r;
@@ -221,17 +282,29 @@ __global__ __launch_bounds__(256) void k_gae_grad(int64_t b, const float* __rest
                                                   const float* __restrict__ row_pos, const float* __restrict__ row_ret,
                                                   float* __restrict__ G, float* __restrict__ row_loss) {
   const int64_t i = blockIdx.x;
-  __shared__ float tot[2];
+  __shared__ float tsh[2][4];
   __shared__ float sh[4];
-  if (threadIdx.x < 2) {   // every workgroup adds the b row sums in the same order
-    const float* src = threadIdx.x == 0 ? row_pos : row_ret;
-    float t = 0.f;
-    for (int64_t r = 0; r < b; ++r) t += src[r];
-    tot[threadIdx.x] = t;
+  {   // every workgroup adds the b row sums in the same order: thread t takes t, t + 256, ...,
+      // the lanes fold in halves, then the 4 wavefronts in order
+    float tp = 0.f, tr = 0.f;
+    for (int64_t r = threadIdx.x; r < b; r += blockDim.x) {
+      tp += row_pos[r];
+      tr += row_ret[r];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      tp += __shfl_down(tp, off);
+      tr += __shfl_down(tr, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      tsh[0][threadIdx.x >> 6] = tp;
+      tsh[1][threadIdx.x >> 6] = tr;
+    }
   }
   __syncthreads();
-  const float num_pos = tot[0];
-  const float ratio = num_pos > 0.f ? tot[1] / num_pos - 1.f : 0.f;
+  const float num_pos = ((tsh[0][0] + tsh[0][1]) + tsh[0][2]) + tsh[0][3];
+  const float tot_ret = ((tsh[1][0] + tsh[1][1]) + tsh[1][2]) + tsh[1][3];
+  const float ratio = num_pos > 0.f ? tot_ret / num_pos - 1.f : 0.f;
   const float inv = 1.f / (float(b) * float(b));
   float loss = 0.f;
   for (int64_t j = threadIdx.x; j < b; j += blockDim.x) {

@@ -434,3 +434,12 @@ extern "C" int sgnn_batch_project_grad_f32(int64_t n_rows, int64_t F, const floa
   return launch_project<true>(n_rows, F, X, ldx, b, idx, slope, dE, ldde, N, dW, lddw, workspace, workspace_bytes,
                               stream);
 }
+
+extern "C" int sgnn_sum_f32(int64_t n, const float* x, float factor, float* out, void* stream) {
+  using sgnn::fail;
+  if (n < 0) return fail(SGNN_ERR_INVALID, "negative size");
+  if (!out || (n > 0 && !x)) return fail(SGNN_ERR_INVALID, "null pointer");
+  hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), n, x, factor, out);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}

@@ -194,7 +194,7 @@ class _SoftmaxXent(torch.autograd.Function):
     launch (``sgnn_softmax_xent_f32``)."""
 
     @staticmethod
-    def forward(ctx, logits, labels, idx):
+    def forward(ctx, logits, labels, idx, unit):
         logits = logits.contiguous()
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         dz = torch.empty_like(logits)
@@ -205,19 +205,20 @@ class _SoftmaxXent(torch.autograd.Function):
                                                      _lib.ptr(dz), C, _lib.ptr(ws), ws.numel() * 4,
                                                      _lib.current_stream(logits.device)))
         ctx.save_for_backward(dz)
+        ctx.unit = unit
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         (dz,) = ctx.saved_tensors
-        return dz * grad_loss, None, None
+        return (dz if ctx.unit else dz * grad_loss), None, None, None
 
 
 class _SqErr(torch.autograd.Function):
     """``scale * ||a - target[idx]||_F^2`` and its gradient in one launch (``sgnn_sq_err_f32``)."""
 
     @staticmethod
-    def forward(ctx, a, target, idx, scale):
+    def forward(ctx, a, target, idx, scale, unit):
         a = a.contiguous()
         loss = torch.empty((), dtype=torch.float32, device=a.device)
         grad = torch.empty_like(a)
@@ -228,30 +229,35 @@ class _SqErr(torch.autograd.Function):
                                                float(scale), _lib.ptr(loss), _lib.ptr(grad), D, _lib.ptr(ws),
                                                ws.numel() * 4, _lib.current_stream(a.device)))
         ctx.save_for_backward(grad)
+        ctx.unit = unit
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         (grad,) = ctx.saved_tensors
-        return grad * grad_loss, None, None, None
+        return (grad if ctx.unit else grad * grad_loss), None, None, None, None
 
 
 _FUSED_LOSS_MAX = 1 << 30      # elements
 
 
-def _cross_entropy(logits, labels, idx):
+# ``unit=True`` on the fused losses is a promise by the caller: the returned loss enters the
+# objective with coefficient 1 and ``backward()`` starts at the objective (gradient 1), as
+# ``_Layer._optimise`` does with the plain sums the layers build.  The backward then hands
+# the gradient it already computed on, instead of launching a multiplication by 1.
+def _cross_entropy(logits, labels, idx, unit=False):
     """``cross_entropy(logits, labels[idx])`` (mean over rows)."""
     if (logits.is_cuda and logits.dtype == torch.float32 and labels.dtype == torch.int64 and labels.is_contiguous()
             and 0 < logits.numel() <= _FUSED_LOSS_MAX):
-        return _SoftmaxXent.apply(logits, labels, idx)
+        return _SoftmaxXent.apply(logits, labels, idx, unit)
     return Fn.cross_entropy(logits, labels[idx])
 
 
-def _squared_error(a, target, idx, scale):
+def _squared_error(a, target, idx, scale, unit=False):
     """``scale * ((a - target[idx]) ** 2).sum()``."""
     if (a.is_cuda and a.dtype == torch.float32 and target.dtype == torch.float32 and target.dim() == 2
             and target.stride(1) == 1 and 0 < a.numel() <= _FUSED_LOSS_MAX):
-        return _SqErr.apply(a, target, idx, scale)
+        return _SqErr.apply(a, target, idx, scale, unit)
     return scale * (a - target[idx]).pow(2).sum()
 
 
@@ -428,13 +434,13 @@ class EmbeddingLayer(_Layer):
                 idx = self._batch(tX.shape[0])
                 emb = self.embed_batch(tX, idx)
                 if tT is None:
-                    loss = _cross_entropy(emb.matmul(self.Wt), tY, idx)
+                    loss = _cross_entropy(emb.matmul(self.Wt), tY, idx, unit=True)
                 else:
-                    loss = _squared_error(emb, tT, idx, eta / emb.shape[0])
+                    loss = _squared_error(emb, tT, idx, eta / emb.shape[0], unit=True)
                 if embedding_target is not None:
                     jdx = self._batch(PX.shape[0])
                     e2 = self.embed_batch(PX, jdx)
-                    loss = loss + _squared_error(e2, embedding_target, jdx, eta / e2.shape[0])
+                    loss = loss + _squared_error(e2, embedding_target, jdx, eta / e2.shape[0], unit=True)
                 return loss
 
             self._optimise(loss_fn, ridge=self.lam)
@@ -451,7 +457,7 @@ class _FusedReconstruction(torch.autograd.Function):
     reduction launches over the b x b block and their backward."""
 
     @staticmethod
-    def forward(ctx, Z, adjacency, overlook, idx, mask_rate, state):
+    def forward(ctx, Z, adjacency, overlook, idx, mask_rate, state, unit=False):
         lib = _lib.load()
         dev = Z.device
         b = Z.shape[0]
@@ -470,14 +476,21 @@ class _FusedReconstruction(torch.autograd.Function):
         G = torch.empty((b, b), dtype=torch.float32, device=dev)
         _lib.check(lib.sgnn_gae_loss_grad_f32(b, _lib.ptr(S), b, _lib.ptr(target), _lib.ptr(retain), _lib.ptr(sums[0]),
                                               _lib.ptr(sums[1]), _lib.ptr(G), _lib.ptr(sums[2]), st))
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(lib.sgnn_sum_f32(b, _lib.ptr(sums[2]), 1.0, _lib.ptr(loss), st))
         ctx.save_for_backward(Zc, G)
+        ctx.unit = unit
         ctx.mark_non_differentiable(target, retain)
-        return sums[2].sum(), target, retain
+        ctx.set_materialize_grads(False)          # no b x b zero blocks for the two auxiliary outputs
+        return loss, target, retain
 
     @staticmethod
     def backward(ctx, grad_loss, _gt, _gr):
+        if grad_loss is None:
+            return (None,) * 7
         Z, G = ctx.saved_tensors
-        return grad_loss * (G + G.t()).matmul(Z), None, None, None, None, None
+        dZ = (G + G.t()).matmul(Z)
+        return (dZ if ctx.unit else grad_loss * dZ), None, None, None, None, None, None
 
 
 class GAELayer(_Layer):
@@ -525,12 +538,12 @@ class GAELayer(_Layer):
                 emb = self.embed_batch(PX, idx)
                 if self.fused_loss:
                     loss = _FusedReconstruction.apply(emb, self.adjacency, self.overlook, idx, self.mask_rate,
-                                                      self._rng_state)[0]
+                                                      self._rng_state, True)[0]
                 else:
                     target = self.adjacency.sample_block(idx, skip_self=True)          # model/SGNN.py:167-170
                     loss = self.reconstruction_loss(self.decode(emb), target, 1 - self._ignore_mask(idx))
                 if embedding_target is not None:
-                    loss = loss + _squared_error(emb, embedding_target, idx, eta / emb.shape[0])
+                    loss = loss + _squared_error(emb, embedding_target, idx, eta / emb.shape[0], unit=True)
                 return loss
 
             self._optimise(loss_fn, lasso=self.lam)                                    # model/SGNN.py:162

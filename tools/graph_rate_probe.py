@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""What a HIP graph replay costs per node on this card: graphs of 1..80 trivial kernels,
+time per replay and per node (GPU side and host issue).  The per-node figure (~1.8 us) is
+the floor under an optimiser iteration of many tiny kernels."""
 import time, torch
 dev = torch.device("cuda:0")
 x = torch.zeros(4096, device=dev)

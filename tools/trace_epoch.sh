@@ -1,5 +1,7 @@
 #!/bin/bash
-# kernel-trace a short epoch and print per-kernel call counts / average durations
+# Run on the GPU box (through gpurun): kernel-trace a short SGNN epoch (tools/sgnn_epoch.py,
+# 300 iterations per layer run) and print call counts / average durations of the kernels an
+# optimiser iteration consists of.   tools/trace_epoch.sh [classification|clustering]
 set -o pipefail
 TASK=${1:-classification}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/epoch_trace_$TASK
