@@ -68,7 +68,7 @@ def test_fused_adam_counts_steps_under_graph_replay(gpu_device):
     np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6)
 
 
-@pytest.mark.parametrize("B,C", [(1, 1), (17, 41), (512, 41), (512, 64), (300, 65), (64, 200), (20000, 41)])
+@pytest.mark.parametrize("B,C", [(1, 1), (17, 41), (512, 41), (512, 64), (1024, 3), (300, 65), (64, 200), (1025, 41), (20000, 41)])
 @pytest.mark.parametrize("indexed", [False, True])
 def test_softmax_xent_matches_torch(gpu_device, B, C, indexed):
     from sgnn_amd.stacked import _cross_entropy
@@ -86,16 +86,18 @@ def test_softmax_xent_matches_torch(gpu_device, B, C, indexed):
     np.testing.assert_allclose(z.grad.cpu().numpy(), z2.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,D", [(1, 1), (512, 128), (512, 64), (100, 130), (30001, 64)])
+@pytest.mark.parametrize("B,D", [(1, 1), (512, 128), (512, 64), (100, 130), (30001, 64), (1024, 128), (7, 4)])
 @pytest.mark.parametrize("indexed", [False, True])
-def test_squared_error_matches_torch(gpu_device, B, D, indexed):
+@pytest.mark.parametrize("strided", [False, True])
+def test_squared_error_matches_torch(gpu_device, B, D, indexed, strided):
     from sgnn_amd.stacked import _squared_error
     g = torch.Generator(device=gpu_device); g.manual_seed(B + D)
     a = torch.randn(B, D, device=gpu_device, generator=g).requires_grad_()
     a2 = a.detach().clone().requires_grad_()
     rows = 4 * B if indexed else B
     wide = torch.randn(rows, D + 6, device=gpu_device, generator=g)
-    target = wide[:, 3:3 + D]                                   # strided rows
+    # strided rows (generic kernels) or a compact block (the one-launch kernel when it is batch-sized)
+    target = wide[:, 3:3 + D] if strided else wide[:, 3:3 + D].contiguous()
     idx = torch.randint(0, rows, (B,), device=gpu_device, generator=g) if indexed else None
     scale = 1000.0 / B
     mine = _squared_error(a, target, idx, scale)
