@@ -258,9 +258,11 @@ int sgnn_sample_block_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, co
  * memory, {seed, counter, 0}; the third word is internal, zero on entry and left zero.
  * The call uses and then increments the counter on the stream, so a captured HIP graph
  * that contains it draws a new batch on every replay.  The permutation is a 4-round Feistel network with cycle walking: a
- * bijection for every (seed, counter), not a cryptographic one.
+ * bijection for every (seed, counter), not a cryptographic one.  With `map` (int64[n] in
+ * device memory, may be NULL) the entries are map[.] of the drawn positions: a batch of the
+ * training nodes, as node ids (model/SGNN.py:412-421 samples rows of processed_X[mask]).
  */
-int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t* out, void* stream);
+int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, const int64_t* map, int64_t* out, void* stream);
 
 /*
  * Reconstruction loss of the graph auto-encoder layer on one batch (model/SGNN.py:138-164,

@@ -60,7 +60,7 @@ SIGNATURES = {
                                      c_void_p]),
     "sgnn_gae_loss_grad_f32": (c_int, [c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
-    "sgnn_batch_indices": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sgnn_batch_indices": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgnn_adam_step_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    c_float, c_float, c_float, c_void_p, c_void_p]),
     "sgnn_loss_workspace_bytes": (c_size_t, [c_int64]),

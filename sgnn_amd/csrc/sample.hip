@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // murmur3 finaliser
 }
 
 __global__ __launch_bounds__(256) void k_batch_indices(int64_t n, int64_t b, unsigned long long* state,
-                                                       int64_t* __restrict__ out) {
+                                                       const int64_t* __restrict__ map, int64_t* __restrict__ out) {
   const uint64_t seed = state[0], counter = state[1];
   int h = 1;
   while ((int64_t(1) << (2 * h)) < n) ++h;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_batch_indices(int64_t n, int64_t b, uns
       }
       x = (uint64_t(L) << h) | Rr;
     } while (int64_t(x) >= n);
-    out[i] = int64_t(x);
+    out[i] = map ? map[x] : int64_t(x);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void k_batch_indices(int64_t n, int64_t b, uns
 
 }  // namespace
 
-extern "C" int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t* out, void* stream) {
+extern "C" int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, const int64_t* map, int64_t* out,
+                                  void* stream) {
   using sgnn::fail;
   if (n <= 0 || b < 0 || b > n) return fail(SGNN_ERR_INVALID, "need 0 <= b <= n, n > 0");
   if (n > (int64_t(1) << 62)) return fail(SGNN_ERR_INVALID, "n too large");
@@ -120,7 +121,7 @@ extern "C" int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, int64_t
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned blocks = unsigned(b < 65536 * 256 ? (b + 255) / 256 : 65536);
   hipLaunchKernelGGL(k_batch_indices, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, n, b,
-                     reinterpret_cast<unsigned long long*>(state), out);
+                     reinterpret_cast<unsigned long long*>(state), map, out);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }

@@ -323,18 +323,22 @@ class _Layer(torch.nn.Module):
     def _lasso(self):
         return self.W.abs().sum() + self.b.abs().sum() + self.U.abs().sum()
 
-    def _batch(self, rows):
+    def _batch(self, rows, row_map=None, out=None):
         """Indices of a batch drawn without replacement: the head of a pseudo-random
         permutation of ``range(rows)`` (model/SGNN.py:115-117 takes the head of
         ``torch.randperm``), from ``sgnn_batch_indices`` — one small kernel instead of a
-        sort of ``rows`` keys, and it draws afresh on every replay of a HIP graph."""
+        sort of ``rows`` keys, and it draws afresh on every replay of a HIP graph.
+        ``row_map`` (int64[rows]) turns the drawn positions into the ids they stand for;
+        ``out`` receives the indices (a slice of a larger index vector, say)."""
         if self._rng_state is None:      # seeded from torch's generator, so torch.manual_seed governs it
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             self._rng_state = torch.tensor([seed, 0, 0], dtype=torch.int64, device=self.device)
         b = min(self.batch_size, rows)
-        out = torch.empty(b, dtype=torch.int64, device=self.device)
-        _lib.check(_lib.load().sgnn_batch_indices(rows, b, _lib.ptr(self._rng_state), _lib.ptr(out),
-                                                  _lib.current_stream(self.device)))
+        if out is None:
+            out = torch.empty(b, dtype=torch.int64, device=self.device)
+        assert out.numel() == b and out.is_contiguous() and (row_map is None or row_map.numel() == rows)
+        _lib.check(_lib.load().sgnn_batch_indices(rows, b, _lib.ptr(self._rng_state), _lib.ptr(row_map),
+                                                  _lib.ptr(out), _lib.current_stream(self.device)))
         return out
 
     # Optimiser iterations recorded into one HIP graph and replayed.  An iteration is
@@ -426,22 +430,28 @@ class EmbeddingLayer(_Layer):
     def run(self, X, embedding_target=None, eta=1, train=True):
         PX = self.propagated(X)
         if train:
-            tX = PX[self.train_mask]
-            tT = None if embedding_target is None else embedding_target[self.train_mask]
-            tY = self.labels[self.train_mask]
+            # The reference samples rows of processed_X[mask] (model/SGNN.py:412-421); here the
+            # drawn positions are mapped to node ids instead, so every batch reads PX, the labels
+            # and the target directly and no masked copies are made.
+            train_rows = torch.nonzero(self.train_mask.to(self.device)).squeeze(1)
+            n_train, n_all = train_rows.numel(), PX.shape[0]
+            b1, b2 = min(self.batch_size, n_train), min(self.batch_size, n_all)
 
             def loss_fn():
-                idx = self._batch(tX.shape[0])
-                emb = self.embed_batch(tX, idx)
-                if tT is None:
-                    loss = _cross_entropy(emb.matmul(self.Wt), tY, idx, unit=True)
-                else:
-                    loss = _squared_error(emb, tT, idx, eta / emb.shape[0], unit=True)
-                if embedding_target is not None:
-                    jdx = self._batch(PX.shape[0])
-                    e2 = self.embed_batch(PX, jdx)
-                    loss = loss + _squared_error(e2, embedding_target, jdx, eta / e2.shape[0], unit=True)
-                return loss
+                if embedding_target is None:
+                    idx = self._batch(n_train, row_map=train_rows)
+                    emb = self.embed_batch(PX, idx)
+                    return _cross_entropy(emb.matmul(self.Wt), self.labels, idx, unit=True)
+                # a batch of training nodes and a batch of all nodes against the target
+                # (model/SGNN.py:421-428): drawn into one index vector, projected in one go
+                both = torch.empty(b1 + b2, dtype=torch.int64, device=self.device)
+                self._batch(n_train, row_map=train_rows, out=both[:b1])
+                self._batch(n_all, out=both[b1:])
+                emb = self.embed_batch(PX, both)
+                if b1 == b2:
+                    return _squared_error(emb, embedding_target, both, eta / b1, unit=True)
+                return (_squared_error(emb[:b1], embedding_target, both[:b1], eta / b1, unit=True)
+                        + _squared_error(emb[b1:], embedding_target, both[b1:], eta / b2, unit=True))
 
             self._optimise(loss_fn, ridge=self.lam)
         return self._finish(X, PX)

@@ -122,7 +122,7 @@ def test_batch_indices_are_a_permutation_head(gpu_device):
 
     def draw(n, b, state):
         out = torch.empty(b, dtype=torch.int64, device=gpu_device)
-        _lib.check(lib.sgnn_batch_indices(n, b, _lib.ptr(state), _lib.ptr(out), _lib.current_stream(gpu_device)))
+        _lib.check(lib.sgnn_batch_indices(n, b, _lib.ptr(state), None, _lib.ptr(out), _lib.current_stream(gpu_device)))
         return out.cpu().numpy()
 
     for n in (1, 2, 5, 64, 1000, 4097, 232_965):

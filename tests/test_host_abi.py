@@ -65,8 +65,8 @@ def test_argument_errors_are_reported_not_crashes():
     assert rc == -1 and b"ldo" in lib.sgnn_last_error()
     assert lib.sgnn_sample_block_f32(4, 4, None, None, None, 0, None, 0, None, 0, None) == 0
     # batch indices / auto-encoder loss / group weights: argument checks come before any launch
-    assert lib.sgnn_batch_indices(5, 6, None, None, None) == -1 and b"b <= n" in lib.sgnn_last_error()
-    assert lib.sgnn_batch_indices(5, 2, None, None, None) == -1 and b"null" in lib.sgnn_last_error()
+    assert lib.sgnn_batch_indices(5, 6, None, None, None, None) == -1 and b"b <= n" in lib.sgnn_last_error()
+    assert lib.sgnn_batch_indices(5, 2, None, None, None, None) == -1 and b"null" in lib.sgnn_last_error()
     assert lib.sgnn_gae_targets_f32(4, 4, None, None, None, None, None, 3, None, 1.5, None,
                                     None, None, None, None, None) == -1 and b"mask_rate" in lib.sgnn_last_error()
     assert lib.sgnn_gae_targets_f32(4, 4, None, None, None, None, None, 0, None, 0.2, None,
