@@ -161,6 +161,7 @@ __device__ __forceinline__ float csr_lookup(const int* __restrict__ colidx, cons
 }
 
 constexpr int kStageCols = 6144, kStageOverlook = 2048;      // 32 KB of LDS per workgroup
+constexpr int kLongPivots = 1024;
 
 // piv[p] = src[p * stride] for p < n, by the whole workgroup, eight loads in flight per thread
 // (issued one at a time, each would cost a trip to HBM: the rows are cold).
@@ -223,8 +224,10 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
   __shared__ int s_cols[kStageCols];
   __shared__ int s_ocols[kStageOverlook];
   const int len = hi0 - lo0, olen = ohi - olo;
-  const int stride = (len + kStageCols - 1) / kStageCols > 1 ? (len + kStageCols - 1) / kStageCols : 1;
-  const int ostride = (olen + kStageOverlook - 1) / kStageOverlook > 1 ? (olen + kStageOverlook - 1) / kStageOverlook : 1;
+  // a row that does not fit is sampled at kLongPivots points only: one CU streaming a hub row of
+  // 10^5 entries through its pivots would take longer than the searches it saves
+  const int stride = len <= kStageCols ? 1 : (len + kLongPivots - 1) / kLongPivots;
+  const int ostride = olen <= kStageOverlook ? 1 : (olen + kLongPivots - 1) / kLongPivots;
   const int n_piv = (len + stride - 1) / stride, n_opiv = (olen + ostride - 1) / ostride;
   stage_pivots(s_cols, n_piv, colidx + lo0, stride);
   stage_pivots(s_ocols, n_opiv, o_colidx + olo, ostride);
