@@ -357,6 +357,21 @@ int sgnn_batch_project_grad_f32(int64_t n_rows, int64_t F, const float* X, int64
                                 const int64_t* idx, float slope, const float* dE, int64_t ldde, int64_t N,
                                 float* dW, int64_t lddw, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * The label head on one batch in two launches (model/SGNN.py:397-399 with its backward):
+ *   logits = E . Wt,  loss[0] = mean_i( logsumexp(logits_i) - logits_i[y_i] ),
+ *   dE = dz . Wt^T,  dWt = E^T . dz,   dz = (softmax(logits) - onehot(y)) / B.
+ * E is B x D (row stride lde), Wt is D x C (row stride ldw), D <= 256, C <= 64 and
+ * 4 (D C + 8 D + 8 C) <= 64 KB of LDS (SGNN_ERR_UNSUPPORTED beyond); y_i = labels[idx[i]] when idx is given, else labels[i].
+ * `workspace`: sgnn_head_xent_workspace_bytes(B, D, C) bytes, contents irrelevant.  Sums are
+ * formed in a fixed order.
+ */
+size_t sgnn_head_xent_workspace_bytes(int64_t B, int64_t D, int64_t C);
+int sgnn_head_xent_f32(int64_t B, int64_t D, int64_t C, const float* E, int64_t lde, const float* Wt, int64_t ldw,
+                       const int64_t* labels, int64_t n_labels, const int64_t* idx, float* loss,
+                       float* dE, int64_t ldde, float* dWt, int64_t lddw,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

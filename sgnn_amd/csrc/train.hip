@@ -161,6 +161,121 @@ __global__ __launch_bounds__(kLossThreads) void k_sq_err(int64_t B, int64_t D, c
 
 
 // ---------------------------------------------------------------------------------
+// The label head on one batch, end to end: logits = E . Wt, their cross-entropy against the
+// labels, and both gradients dE = dz . Wt^T and dWt = E^T . dz (model/SGNN.py:397-399 and its
+// backward).  E is b x D (D <= 256), Wt is D x C (C <= 64): a few hundred KFLOP that stock
+// kernels spread over five launches (GEMM, softmax, nll, two GEMMs).  Here a workgroup keeps
+// Wt in LDS and takes kHeadRows rows; a wavefront owns a row at a time with lane c holding
+// class c.  dWt needs all rows: every workgroup writes its share and k_head_finish adds the
+// shares (and the rows' loss terms) in a fixed order in a second launch.
+constexpr int kHeadRows = 4;                     // one per wavefront
+constexpr int kHeadMaxD = 256, kHeadMaxC = 64;
+
+__global__ __launch_bounds__(256) void k_head_xent(int64_t B, int D, int C, const float* __restrict__ E, int64_t lde,
+                                                   const float* __restrict__ Wt, int64_t ldw,
+                                                   const int64_t* __restrict__ labels, const int64_t* __restrict__ idx,
+                                                   int64_t n_labels, float* __restrict__ dE, int64_t ldde,
+                                                   float* __restrict__ row_loss, float* __restrict__ dWt_part) {
+  extern __shared__ float smem[];
+  float* sW = smem;                               // [D][C]
+  float* sE = sW + D * C;                         // [kHeadRows][D]
+  float* sZ = sE + kHeadRows * D;                 // [kHeadRows][C]   dz
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t r0 = int64_t(blockIdx.x) * kHeadRows;
+  // (k, c) of element e = t, t + 256, ... of a D x C array, stepped without dividing every time
+  const int step_k = 256 / C, step_c = 256 % C;
+  {
+    int k = t / C, c = t % C;
+    for (int e = t; e < D * C; e += 256) {
+      sW[e] = Wt[int64_t(k) * ldw + c];
+      k += step_k; c += step_c;
+      if (c >= C) { c -= C; ++k; }
+    }
+  }
+  for (int lr = 0; lr < kHeadRows; ++lr) {
+    const int64_t r = r0 + lr;
+    for (int k = t; k < D; k += 256) sE[lr * D + k] = r < B ? E[r * lde + k] : 0.f;
+  }
+  __syncthreads();
+  const float inv_b = 1.f / float(B);
+  for (int lr = w; lr < kHeadRows; lr += 4) {     // this wavefront's rows
+    const int64_t r = r0 + lr;
+    if (r >= B) {                                 // uniform over the wavefront
+      if (lane < C) sZ[lr * C + lane] = 0.f;
+      continue;
+    }
+    const float* e = sE + lr * D;
+    float z = 0.f;
+    if (lane < C) {
+      float z1 = 0.f, z2 = 0.f, z3 = 0.f;
+      int k = 0;
+      for (; k + 3 < D; k += 4) {                 // four independent chains
+        z = fmaf(e[k], sW[k * C + lane], z);
+        z1 = fmaf(e[k + 1], sW[(k + 1) * C + lane], z1);
+        z2 = fmaf(e[k + 2], sW[(k + 2) * C + lane], z2);
+        z3 = fmaf(e[k + 3], sW[(k + 3) * C + lane], z3);
+      }
+      for (; k < D; ++k) z = fmaf(e[k], sW[k * C + lane], z);
+      z = (z + z1) + (z2 + z3);
+    }
+    const float zm = lane < C ? z : -INFINITY;
+    const float mx = wave_max(zm);
+    const float ex = lane < C ? expf(z - mx) : 0.f;
+    const float sum = wave_sum(ex);
+    const int64_t at = idx ? idx[r] : r;
+    const int64_t y = (at >= 0 && at < n_labels) ? labels[at] : -1;
+    const float dz = (ex / sum - (lane == y ? 1.f : 0.f)) * inv_b;
+    if (lane < C) sZ[lr * C + lane] = dz;
+    const float zy = __shfl(z, (y >= 0 && y < C) ? int(y) : 0);
+    if (lane == 0) row_loss[r] = (y >= 0 && y < C) ? mx + logf(sum) - zy : 0.f;
+    // dE[r][k] = sum_c dz[c] * Wt[k][c]; the wavefront's own dz row is visible to it after the store
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < D; k += 64) {
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) acc = fmaf(sZ[lr * C + c], sW[k * C + c], acc);
+      dE[r * ldde + k] = acc;
+    }
+  }
+  __syncthreads();
+  float* mine = dWt_part + int64_t(blockIdx.x) * D * C;
+  int k = t / C, c = t % C;
+  for (int e = t; e < D * C; e += 256) {          // dWt share of these rows
+    float acc = 0.f;
+#pragma unroll
+    for (int lr = 0; lr < kHeadRows; ++lr) acc = fmaf(sE[lr * D + k], sZ[lr * C + c], acc);
+    mine[e] = acc;
+    k += step_k; c += step_c;
+    if (c >= C) { c -= C; ++k; }
+  }
+}
+
+// dWt[k][c] = sum over the workgroups' shares in a fixed order; the last workgroup of this
+// launch adds the rows' loss terms (one wavefront, fixed order).
+__global__ __launch_bounds__(256) void k_head_finish(int64_t B, int D, int C, int shares,
+                                                     const float* __restrict__ dWt_part, float* __restrict__ dWt,
+                                                     int64_t lddw, const float* __restrict__ row_loss,
+                                                     float* __restrict__ loss) {
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x >= 64) return;
+    float s = 0.f;
+    for (int64_t r = threadIdx.x; r < B; r += 64) s += row_loss[r];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s / float(B);
+    return;
+  }
+  // four lanes per element: lane q adds shares q, q + 4, ... in order, then the four fold
+  const int e = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+  float acc = 0.f;
+  if (e < D * C) {
+#pragma unroll 8
+    for (int z = q; z < shares; z += 4) acc += dWt_part[int64_t(z) * D * C + e];
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  if (e < D * C && q == 0) dWt[lddw == C ? int64_t(e) : int64_t(e / C) * lddw + e % C] = acc;
+}
+
+// ---------------------------------------------------------------------------------
 // The layer's projection of one batch, E = act(X[idx]) . W, and its weight gradient
 // dW = act(X[idx])^T . dE, with the row gather and the inner activation
 // act(x) = x > 0 ? x : slope * x applied while the operand is loaded
@@ -440,6 +555,41 @@ extern "C" int sgnn_sum_f32(int64_t n, const float* x, float factor, float* out,
   if (n < 0) return fail(SGNN_ERR_INVALID, "negative size");
   if (!out || (n > 0 && !x)) return fail(SGNN_ERR_INVALID, "null pointer");
   hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), n, x, factor, out);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+extern "C" size_t sgnn_head_xent_workspace_bytes(int64_t B, int64_t D, int64_t C) {
+  if (B <= 0 || D <= 0 || C <= 0) return 0;
+  const int64_t shares = (B + kHeadRows - 1) / kHeadRows;
+  return size_t(B + shares * D * C) * sizeof(float);
+}
+
+extern "C" int sgnn_head_xent_f32(int64_t B, int64_t D, int64_t C, const float* E, int64_t lde, const float* Wt,
+                                  int64_t ldw, const int64_t* labels, int64_t n_labels, const int64_t* idx, float* loss,
+                                  float* dE, int64_t ldde, float* dWt, int64_t lddw, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  using sgnn::fail;
+  if (B <= 0 || D <= 0 || C <= 0) return fail(SGNN_ERR_INVALID, "need B > 0, D > 0, C > 0");
+  if (D > kHeadMaxD || C > kHeadMaxC) return fail(SGNN_ERR_UNSUPPORTED, "label head larger than 256 x 64");
+  if (B > (int64_t(1) << 24)) return fail(SGNN_ERR_INVALID, "batch too large");
+  if (lde < D || ldde < D || ldw < C || lddw < C) return fail(SGNN_ERR_INVALID, "row stride smaller than the width");
+  if (n_labels < 0 || (!idx && n_labels < B)) return fail(SGNN_ERR_INVALID, "fewer labels than rows");
+  if (!E || !Wt || !labels || !loss || !dE || !dWt || !workspace) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (workspace_bytes < sgnn_head_xent_workspace_bytes(B, D, C))
+    return fail(SGNN_ERR_WORKSPACE, "label-head workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t shares = (B + kHeadRows - 1) / kHeadRows;
+  float* rows = static_cast<float*>(workspace);
+  float* part = rows + B;
+  const size_t lds = size_t(D * C + kHeadRows * D + kHeadRows * C) * sizeof(float);
+  if (lds > 64 * 1024) return fail(SGNN_ERR_UNSUPPORTED, "label head does not fit 64 KB of LDS");
+  hipLaunchKernelGGL(k_head_xent, dim3(unsigned(shares)), dim3(256), lds, st, B, int(D), int(C), E, lde, Wt, ldw, labels,
+                     idx, n_labels, dE, ldde, rows, part);
+  HIP_TRY(hipGetLastError());
+  const unsigned blocks = unsigned((D * C + 63) / 64) + 1;
+  hipLaunchKernelGGL(k_head_finish, dim3(blocks), dim3(256), 0, st, B, int(D), int(C), int(shares), part, dWt, lddw,
+                     rows, loss);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }

@@ -214,6 +214,47 @@ class _SoftmaxXent(torch.autograd.Function):
         return (dz if ctx.unit else dz * grad_loss), None, None, None
 
 
+class _HeadXent(torch.autograd.Function):
+    """``cross_entropy(E @ Wt, labels[idx])`` with both gradients from ``sgnn_head_xent_f32``
+    (two launches instead of GEMM, softmax, nll and two backward GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, E, Wt, labels, idx, unit):
+        E = E.contiguous()
+        B, D = E.shape
+        C = Wt.shape[1]
+        dev = E.device
+        lib = _lib.load()
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dE = torch.empty_like(E)
+        dWt = torch.empty(D, C, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.sgnn_head_xent_workspace_bytes(B, D, C) // 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.sgnn_head_xent_f32(B, D, C, _lib.ptr(E), D, _lib.ptr(Wt), Wt.stride(0), _lib.ptr(labels),
+                                          labels.numel(), _lib.ptr(idx) if idx is not None else None, _lib.ptr(loss),
+                                          _lib.ptr(dE), D, _lib.ptr(dWt), C, _lib.ptr(ws), ws.numel() * 4,
+                                          _lib.current_stream(dev)))
+        ctx.save_for_backward(dE, dWt)
+        ctx.unit = unit
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        dE, dWt = ctx.saved_tensors
+        if ctx.unit:
+            return dE, dWt, None, None, None
+        return dE * grad_loss, dWt * grad_loss, None, None, None
+
+
+def _head_cross_entropy(E, Wt, labels, idx, unit=False):
+    """``cross_entropy(E @ Wt, labels[idx])``."""
+    if (E.is_cuda and E.dtype == torch.float32 and E.dim() == 2 and Wt.dtype == torch.float32 and Wt.stride(1) == 1
+            and labels.dtype == torch.int64 and labels.is_contiguous() and E.shape[0] > 0
+            and E.shape[1] <= 256 and Wt.shape[1] <= 64
+            and 4 * (E.shape[1] * Wt.shape[1] + 8 * E.shape[1] + 8 * Wt.shape[1]) <= 65536):
+        return _HeadXent.apply(E, Wt, labels, idx, unit)
+    return _cross_entropy(E.matmul(Wt), labels, idx, unit)
+
+
 class _SqErr(torch.autograd.Function):
     """``scale * ||a - target[idx]||_F^2`` and its gradient in one launch (``sgnn_sq_err_f32``)."""
 
@@ -441,7 +482,7 @@ class EmbeddingLayer(_Layer):
                 if embedding_target is None:
                     idx = self._batch(n_train, row_map=train_rows)
                     emb = self.embed_batch(PX, idx)
-                    return _cross_entropy(emb.matmul(self.Wt), self.labels, idx, unit=True)
+                    return _head_cross_entropy(emb, self.Wt, self.labels, idx, unit=True)
                 # a batch of training nodes and a batch of all nodes against the target
                 # (model/SGNN.py:421-428): drawn into one index vector, projected in one go
                 both = torch.empty(b1 + b2, dtype=torch.int64, device=self.device)

@@ -203,3 +203,30 @@ def test_embed_batch_equals_the_unfused_layer(gpu_device):
         g1 = layer.W.grad.clone(); layer.W.grad = None
         plain.sum().backward()
         np.testing.assert_allclose(g1.cpu().numpy(), layer.W.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,D,C", [(512, 128, 41), (512, 64, 41), (5, 3, 2), (100, 200, 64), (1000, 128, 7), (9, 1, 1)])
+@pytest.mark.parametrize("indexed", [False, True])
+def test_label_head_matches_torch(gpu_device, B, D, C, indexed):
+    from sgnn_amd.stacked import _head_cross_entropy
+    g = torch.Generator(device=gpu_device); g.manual_seed(B + D + C)
+    E = torch.randn(B, D, device=gpu_device, generator=g).requires_grad_()
+    Wt = (torch.randn(D, C, device=gpu_device, generator=g) * 0.5).requires_grad_()
+    E2, Wt2 = E.detach().clone().requires_grad_(), Wt.detach().clone().requires_grad_()
+    n_lab = 3 * B if indexed else B
+    labels = torch.randint(0, C, (n_lab,), device=gpu_device, generator=g)
+    idx = torch.randperm(n_lab, device=gpu_device, generator=g)[:B] if indexed else None
+    mine = _head_cross_entropy(E, Wt, labels, idx)
+    ref = Fn.cross_entropy(E2.double().matmul(Wt2.double()), labels[idx] if indexed else labels)
+    (2.0 * mine).backward()
+    (2.0 * ref).backward()
+    assert abs(mine.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    for got, want in ((E.grad, E2.grad), (Wt.grad, Wt2.grad)):
+        err = (got.double() - want.double()).norm() / want.double().norm().clamp_min(1e-30)
+        assert float(err) <= 1e-5, float(err)
+    # the unfused route (wide heads) gives the same thing
+    wide = torch.randn(B, 300, device=gpu_device, generator=g)
+    Ww = torch.randn(300, C, device=gpu_device, generator=g) * 0.1
+    a = _head_cross_entropy(wide, Ww, labels, idx)
+    b = Fn.cross_entropy(wide.matmul(Ww), labels[idx] if indexed else labels)
+    assert abs(a.item() - b.item()) <= 1e-5 * max(1.0, abs(b.item()))
