@@ -151,3 +151,14 @@ def test_batch_indices_are_a_permutation_head(gpu_device):
     assert first.max() <= 6                                    # no id owns the first slot
     with pytest.raises(_lib.SgnnHipError):
         draw(5, 6, state)
+    # with a map the drawn positions come back as the ids they stand for, into a slice of a longer vector
+    ids = torch.arange(0, 3 * 50, 3, dtype=torch.int64, device=gpu_device) + 7
+    s1 = torch.tensor([5, 0, 0], dtype=torch.int64, device=gpu_device)
+    s2 = torch.tensor([5, 0, 0], dtype=torch.int64, device=gpu_device)
+    plain = draw(50, 20, s1)
+    both = torch.full((30,), -1, dtype=torch.int64, device=gpu_device)
+    _lib.check(lib.sgnn_batch_indices(50, 20, _lib.ptr(s2), _lib.ptr(ids), _lib.ptr(both[10:]),
+                                      _lib.current_stream(gpu_device)))
+    got = both.cpu().numpy()
+    assert (got[:10] == -1).all() and np.array_equal(got[10:], ids.cpu().numpy()[plain])
+    assert int(s2[1]) == 1 and int(s2[2]) == 0
