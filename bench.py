@@ -350,8 +350,10 @@ def main():
                 "traffic": load_traffic(args.workload) if world == 1 else None,
                 "algorithmic_bytes": b_alg,
                 "kernel_ms": ev_ms,                           # HIP events around the K steps / K
-                "kernels_in_step": ("k_row_scale + k_rg_spmm + k_rg_combine (rocprof: 0.19 + 9.65 + 0.58 ms)"
-                                    if (world == 1 and R) else "see profiles/"),
+                "kernels_in_step": ("k_row_scale + k_rg_spmm + k_rg_combine"
+                                    + (" (rocprof, profiles/r01_reddit_f602_rowgroup_x4.json: 0.19 + 9.65 + 0.58 ms)"
+                                       if args.workload == "reddit" and world == 1 else "")) if R
+                                   else "k_spmm (+ k_row_scale)",
                 "gather_bytes_no_reuse": nnz * F * 4 * args.order,
             },
         }
