@@ -339,23 +339,31 @@ int sgnn_sq_err_f32(int64_t B, int64_t D, const float* a, int64_t lda, const flo
 /*
  * A layer's projection of one batch with the row gather and the inner activation folded
  * into the operand load (model/SGNN.py:73-78 applied to the rows model/SGNN.py:106-121
- * picked, while the layer's U is the identity):
- *   sgnn_batch_project_f32      E  (b x N) = act(X[idx]) . W        W  is F x N, row stride ldw
- *   sgnn_batch_project_grad_f32 dW (F x N) = act(X[idx])^T . dE     dE is b x N, row stride ldde
- * act(x) = x > 0 ? x : slope * x (slope 1 = linear, 0 = relu, else leaky_relu); X has n_rows
- * rows of F floats with row stride ldx; idx is int64[b], an id outside [0, n_rows) reads as
- * a zero row.  fp32 throughout, fused multiply-adds in a fixed order: the reduction
- * dimension is cut into chunks handled by different workgroups whose partial tiles go through
- * `workspace` (sgnn_batch_project_workspace_bytes bytes, contents irrelevant; `grad` selects
- * which of the two calls the size is for) and are added in chunk order by a second launch.
+ * picked):
+ *   sgnn_batch_project_f32            E  (b x N) = act(X[idx]) . W        W  is F x N, row stride ldw
+ *   sgnn_batch_project_grad_f32       dW (F x N) = act(X[idx])^T . dE     dE is b x N, row stride ldde
+ *   sgnn_batch_project_input_grad_f32 dA (b x F) = (dE . W^T) * act'(pre) pre is b x F or NULL (no factor)
+ * act(x) = x > 0 ? x : slope * x (slope 1 = linear, 0 = relu, else leaky_relu), act' its
+ * derivative (1 or slope); X has n_rows rows of F floats with row stride ldx; idx is int64[b],
+ * an id outside [0, n_rows) reads as a zero row, idx NULL = rows 0..b-1 of X (a dense operand).
+ * With U the identity the first two are the whole layer; while U is trained they serve
+ * X[idx] . U / dU (slope 1) and, on the dense XU, act(XU) . W / dW, and the third gives dXU.
+ * fp32 throughout, fused multiply-adds in a fixed order: the reduction dimension is cut into
+ * chunks handled by different workgroups whose partial tiles go through `workspace`
+ * (sgnn_batch_project_workspace_bytes bytes, contents irrelevant; `which` = 0, 1, 2 for the
+ * three calls in the order above) and are added in chunk order by a second launch.
  */
-size_t sgnn_batch_project_workspace_bytes(int64_t b, int64_t F, int64_t N, int grad);
+size_t sgnn_batch_project_workspace_bytes(int64_t b, int64_t F, int64_t N, int which);
 int sgnn_batch_project_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b, const int64_t* idx,
                            float slope, const float* W, int64_t ldw, int64_t N, float* E, int64_t lde,
                            void* workspace, size_t workspace_bytes, void* stream);
 int sgnn_batch_project_grad_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b,
                                 const int64_t* idx, float slope, const float* dE, int64_t ldde, int64_t N,
                                 float* dW, int64_t lddw, void* workspace, size_t workspace_bytes, void* stream);
+int sgnn_batch_project_input_grad_f32(int64_t b, int64_t F, int64_t N, const float* dE, int64_t ldde,
+                                      const float* W, int64_t ldw, const float* pre, int64_t ldpre, float slope,
+                                      float* dA, int64_t ldda, void* workspace, size_t workspace_bytes,
+                                      void* stream);
 
 /*
  * The label head on one batch in two launches (model/SGNN.py:397-399 with its backward):

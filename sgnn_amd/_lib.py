@@ -70,6 +70,9 @@ SIGNATURES = {
                                    c_void_p]),
     "sgnn_sum_f32": (c_int, [c_int64, c_void_p, c_float, c_void_p, c_void_p]),
     "sgnn_batch_project_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "sgnn_batch_project_input_grad_f32": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                                  c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p, c_size_t,
+                                                  c_void_p]),
     "sgnn_batch_project_f32": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_float, c_void_p, c_int64,
                                        c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "sgnn_batch_project_grad_f32": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_float, c_void_p,

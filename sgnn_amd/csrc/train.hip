@@ -293,24 +293,27 @@ constexpr int kChunk = 32;                        // reduction depth handled by 
 // long ones whose every K-slab costs a global-memory round trip.  Each thread forms a 4 x 4
 // block of its workgroup's 64 x 64 partial tile; k_project_sum then adds the partial tiles in
 // chunk order (a launch of its own rather than a device-wide fence inside this one).
-template <bool GRAD>
-__global__ __launch_bounds__(256) void k_batch_project(int64_t n_rows, int64_t F, const float* __restrict__ X,
-                                                       int64_t ldx, int64_t b, const int64_t* __restrict__ idx,
-                                                       float slope, const float* __restrict__ Bm, int64_t ldb,
-                                                       int64_t N, float* __restrict__ C, int64_t ldc,
+template <bool GRAD, bool TRANSB>
+__global__ __launch_bounds__(256) void k_batch_project(int64_t M, int64_t N, int64_t K, int64_t n_rows,
+                                                       const float* __restrict__ X, int64_t ldx,
+                                                       const int64_t* __restrict__ idx, float slope,
+                                                       const float* __restrict__ Bm, int64_t ldb,
+                                                       float* __restrict__ C, int64_t ldc,
                                                        float4* __restrict__ partial) {
-  // forward: C[b x N] = A . Bm,  A(m, k) = act(X[idx[m]][k]),  M = b, K = F,  Bm = W  (F x N)
-  // GRAD   : C[F x N] = A . Bm,  A(m, k) = act(X[idx[k]][m]),  M = F, K = b,  Bm = dE (b x N)
+  // C[M x N] = A . B over K, one 64 x 64 tile and one 32-deep chunk of K per workgroup.
+  //   forward    : A(m, k) = act(X[idx[m]][k])           B(k, n) = Bm[k][n]   (W,  K x N)
+  //   GRAD       : A(m, k) = act(X[idx[k]][m])           B(k, n) = Bm[k][n]   (dE, K x N)
+  //   TRANSB     : A(m, k) = X[m][k] (idx NULL, slope 1) B(k, n) = Bm[n][k]   (W,  N x K)
+  // idx NULL = the rows of X in order.
   __shared__ __align__(16) float As[kChunk][kT + 4];   // As[k][m]
   __shared__ __align__(16) float Bs[kChunk][kT + 4];   // Bs[k][n]
-  const int64_t M = GRAD ? F : b, K = GRAD ? b : F;
   const int64_t m0 = int64_t(blockIdx.y) * kT, n0 = int64_t(blockIdx.x) * kT;
   const int64_t k0 = int64_t(blockIdx.z) * kChunk;
   const int t = threadIdx.x;
   if (!GRAD) {                                    // row t / 4 of the tile, 8 consecutive k
     const int lm = t >> 2, lk = (t & 3) * 8;
     const int64_t m = m0 + lm;
-    int64_t r = m < b ? idx[m] : -1;
+    int64_t r = m < M ? (idx ? idx[m] : m) : -1;
     if (r >= n_rows) r = -1;
     const float* src = X + r * ldx + k0 + lk;
 #pragma unroll
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void k_batch_project(int64_t n_rows, int64_t F
   } else {                                        // batch position t / 8 of the chunk, 8 consecutive features
     const int lk = t >> 3, lm = (t & 7) * 8;
     const int64_t k = k0 + lk;
-    int64_t r = k < K ? idx[k] : -1;
+    int64_t r = k < K ? (idx ? idx[k] : k) : -1;
     if (r >= n_rows) r = -1;
     const float* src = X + r * ldx + m0 + lm;
 #pragma unroll
@@ -330,12 +333,18 @@ __global__ __launch_bounds__(256) void k_batch_project(int64_t n_rows, int64_t F
       As[lk][lm + e] = x > 0.f ? x : slope * x;
     }
   }
-  {
+  if (!TRANSB) {
     const int lk = t >> 3, ln = (t & 7) * 8;
     const int64_t k = k0 + lk;
     const float* src = Bm + k * ldb + n0 + ln;
 #pragma unroll
     for (int e = 0; e < 8; ++e) Bs[lk][ln + e] = (k < K && n0 + ln + e < N) ? src[e] : 0.f;
+  } else {                                        // row n of Bm, 8 consecutive k
+    const int ln = t >> 2, lk = (t & 3) * 8;
+    const int64_t n = n0 + ln;
+    const float* src = Bm + n * ldb + k0 + lk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Bs[lk + e][ln] = (n < N && k0 + lk + e < K) ? src[e] : 0.f;
   }
   __syncthreads();
   const int ty = t >> 4, tx = t & 15;             // 4 x 4 outputs at (4 ty, 4 tx)
@@ -374,7 +383,8 @@ __global__ __launch_bounds__(256) void k_batch_project(int64_t n_rows, int64_t F
 // workgroup per (tile, i), so every thread adds one float4 per chunk.
 __global__ __launch_bounds__(256) void k_project_sum(int64_t M, int64_t N, int splits,
                                                      const float4* __restrict__ partial, float* __restrict__ C,
-                                                     int64_t ldc) {
+                                                     int64_t ldc, const float* __restrict__ pre, int64_t ldpre,
+                                                     float slope) {
   const int64_t tile = int64_t(blockIdx.y) * gridDim.x + blockIdx.x, tiles = int64_t(gridDim.x) * gridDim.y;
   const int t = threadIdx.x, ty = t >> 4, tx = t & 15, i = blockIdx.z;
   const float4* src = partial + tile * 1024 + i * 256 + t;
@@ -387,10 +397,14 @@ __global__ __launch_bounds__(256) void k_project_sum(int64_t M, int64_t N, int s
   }
   const int64_t m = int64_t(blockIdx.y) * kT + 4 * ty + i, n = int64_t(blockIdx.x) * kT + 4 * tx;
   if (m >= M) return;
-  if (n < N) C[m * ldc + n] = acc.x;
-  if (n + 1 < N) C[m * ldc + n + 1] = acc.y;
-  if (n + 2 < N) C[m * ldc + n + 2] = acc.z;
-  if (n + 3 < N) C[m * ldc + n + 3] = acc.w;
+  float out[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (n + j >= N) break;
+    // pre given: times act'(pre) — the chain rule through act(x) = x > 0 ? x : slope * x
+    if (pre != nullptr && !(pre[m * ldpre + n + j] > 0.f)) out[j] *= slope;
+    C[m * ldc + n + j] = out[j];
+  }
 }
 
 }  // namespace
@@ -490,41 +504,47 @@ int check_project(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_
   using sgnn::fail;
   if (n_rows < 0 || F <= 0 || b <= 0 || N <= 0) return fail(SGNN_ERR_INVALID, "need F > 0, b > 0, N > 0");
   if (ldx < F) return fail(SGNN_ERR_INVALID, "ldx smaller than the feature width");
-  if (!X || !idx) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (!X) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (!idx && n_rows < b) return fail(SGNN_ERR_INVALID, "fewer rows than the batch and no index list");
   if (b > 65535 * int64_t(kT) || F > 65535 * int64_t(kT) || N > (int64_t(1) << 20) * kT)
     return fail(SGNN_ERR_INVALID, "dimension too large for one launch");
   return SGNN_OK;
 }
-template <bool GRAD>
-int launch_project(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b, const int64_t* idx, float slope,
-                   const float* Bm, int64_t ldb, int64_t N, float* C, int64_t ldc, void* ws, size_t ws_bytes,
-                   void* stream) {
+template <bool GRAD, bool TRANSB>
+int launch_project(int64_t M, int64_t N, int64_t K, int64_t n_rows, const float* X, int64_t ldx, const int64_t* idx,
+                   float slope, const float* Bm, int64_t ldb, float* C, int64_t ldc, const float* pre, int64_t ldpre,
+                   float pre_slope, void* ws, size_t ws_bytes, void* stream) {
   using sgnn::fail;
-  const ProjectGrid g = GRAD ? project_grid(F, N, b) : project_grid(b, N, F);
-  if (g.splits > 1) {
+  const ProjectGrid g = project_grid(M, N, K);
+  const bool staged = g.splits > 1 || pre != nullptr;        // the derivative mask is applied by the summing launch
+  if (staged) {
     if (ws_bytes < size_t(g.splits * g.tiles_m * g.tiles_n) * 1024 * sizeof(float4))
       return fail(SGNN_ERR_WORKSPACE, "projection workspace too small");
     if (!ws) return fail(SGNN_ERR_INVALID, "null pointer");
     if (g.splits > 65535) return fail(SGNN_ERR_INVALID, "dimension too large for one launch");
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(unsigned(g.tiles_n), unsigned(g.tiles_m), unsigned(g.splits));
-  hipLaunchKernelGGL(k_batch_project<GRAD>, grid, dim3(256), 0, st, n_rows, F, X, ldx, b, idx, slope, Bm, ldb, N, C,
-                     ldc, static_cast<float4*>(ws));
+  // with a single chunk and a mask the partial path is forced by a grid of depth 2 whose second chunk is empty
+  const unsigned depth = unsigned(staged && g.splits == 1 ? 2 : g.splits);
+  const dim3 grid(unsigned(g.tiles_n), unsigned(g.tiles_m), depth);
+  hipLaunchKernelGGL((k_batch_project<GRAD, TRANSB>), grid, dim3(256), 0, st, M, N, K, n_rows, X, ldx, idx, slope, Bm,
+                     ldb, C, ldc, static_cast<float4*>(ws));
   HIP_TRY(hipGetLastError());
-  if (g.splits > 1) {
-    hipLaunchKernelGGL(k_project_sum, dim3(unsigned(g.tiles_n), unsigned(g.tiles_m), 4), dim3(256), 0, st, GRAD ? F : b, N,
-                       int(g.splits), static_cast<const float4*>(ws), C, ldc);
+  if (staged) {
+    hipLaunchKernelGGL(k_project_sum, dim3(unsigned(g.tiles_n), unsigned(g.tiles_m), 4), dim3(256), 0, st, M, N,
+                       int(depth), static_cast<const float4*>(ws), C, ldc, pre, ldpre, pre_slope);
     HIP_TRY(hipGetLastError());
   }
   return SGNN_OK;
 }
 }  // namespace
 
-extern "C" size_t sgnn_batch_project_workspace_bytes(int64_t b, int64_t F, int64_t N, int grad) {
+extern "C" size_t sgnn_batch_project_workspace_bytes(int64_t b, int64_t F, int64_t N, int which) {
   if (b <= 0 || F <= 0 || N <= 0) return 0;
-  const ProjectGrid g = grad ? project_grid(F, N, b) : project_grid(b, N, F);
-  return g.splits > 1 ? size_t(g.splits * g.tiles_m * g.tiles_n) * 1024 * sizeof(float4) : 0;
+  // which: 0 = sgnn_batch_project_f32, 1 = sgnn_batch_project_grad_f32, 2 = sgnn_batch_project_input_grad_f32
+  const ProjectGrid g = which == 1 ? project_grid(F, N, b) : which == 2 ? project_grid(b, F, N) : project_grid(b, N, F);
+  const int64_t depth = which == 2 && g.splits == 1 ? 2 : g.splits;
+  return (depth > 1) ? size_t(depth * g.tiles_m * g.tiles_n) * 1024 * sizeof(float4) : 0;
 }
 
 extern "C" int sgnn_batch_project_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b,
@@ -534,8 +554,8 @@ extern "C" int sgnn_batch_project_f32(int64_t n_rows, int64_t F, const float* X,
   if (int rc = check_project(n_rows, F, X, ldx, b, idx, N)) return rc;
   if (ldw < N || lde < N) return fail(SGNN_ERR_INVALID, "row stride smaller than the output width");
   if (!W || !E) return fail(SGNN_ERR_INVALID, "null pointer");
-  return launch_project<false>(n_rows, F, X, ldx, b, idx, slope, W, ldw, N, E, lde, workspace, workspace_bytes,
-                               stream);
+  return launch_project<false, false>(b, N, F, n_rows, X, ldx, idx, slope, W, ldw, E, lde, nullptr, 0, 1.f, workspace,
+                                      workspace_bytes, stream);
 }
 
 extern "C" int sgnn_batch_project_grad_f32(int64_t n_rows, int64_t F, const float* X, int64_t ldx, int64_t b,
@@ -546,8 +566,22 @@ extern "C" int sgnn_batch_project_grad_f32(int64_t n_rows, int64_t F, const floa
   if (int rc = check_project(n_rows, F, X, ldx, b, idx, N)) return rc;
   if (ldde < N || lddw < N) return fail(SGNN_ERR_INVALID, "row stride smaller than the output width");
   if (!dE || !dW) return fail(SGNN_ERR_INVALID, "null pointer");
-  return launch_project<true>(n_rows, F, X, ldx, b, idx, slope, dE, ldde, N, dW, lddw, workspace, workspace_bytes,
-                              stream);
+  return launch_project<true, false>(F, N, b, n_rows, X, ldx, idx, slope, dE, ldde, dW, lddw, nullptr, 0, 1.f,
+                                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int sgnn_batch_project_input_grad_f32(int64_t b, int64_t F, int64_t N, const float* dE, int64_t ldde,
+                                                 const float* W, int64_t ldw, const float* pre, int64_t ldpre,
+                                                 float slope, float* dA, int64_t ldda, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  using sgnn::fail;
+  if (b <= 0 || F <= 0 || N <= 0) return fail(SGNN_ERR_INVALID, "need b > 0, F > 0, N > 0");
+  if (ldde < N || ldw < N || ldda < F || (pre && ldpre < F))
+    return fail(SGNN_ERR_INVALID, "row stride smaller than the width");
+  if (!dE || !W || !dA) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (b > 65535 * int64_t(kT) || F > (int64_t(1) << 20) * kT) return fail(SGNN_ERR_INVALID, "dimension too large for one launch");
+  return launch_project<false, true>(b, F, N, b, dE, ldde, nullptr, 1.f, W, ldw, dA, ldda, pre, ldpre, slope, workspace,
+                                     workspace_bytes, stream);
 }
 
 extern "C" int sgnn_sum_f32(int64_t n, const float* x, float factor, float* out, void* stream) {

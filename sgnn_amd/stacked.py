@@ -175,6 +175,46 @@ class _BatchProject(torch.autograd.Function):
         return None, None, dW, None
 
 
+class _DenseProject(torch.autograd.Function):
+    """``act(A) @ W`` for a dense batch ``A`` that needs its own gradient (``A = X[idx] @ U``
+    while U is trained): the projection kernel with no index list, ``dW`` the same way and
+    ``dA = (dE @ W.T) * act'(A)`` from its transposed-operand variant."""
+
+    @staticmethod
+    def forward(ctx, A, W, slope):
+        A = A.contiguous()
+        b, (F, N) = A.shape[0], W.shape
+        lib, dev = _lib.load(), A.device
+        E = torch.empty(b, N, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.sgnn_batch_project_workspace_bytes(b, F, N, 0) // 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.sgnn_batch_project_f32(b, F, _lib.ptr(A), F, b, None, float(slope), _lib.ptr(W), W.stride(0), N,
+                                              _lib.ptr(E), N, _lib.ptr(ws), ws.numel() * 4, _lib.current_stream(dev)))
+        ctx.save_for_backward(A, W)
+        ctx.slope = float(slope)
+        return E
+
+    @staticmethod
+    def backward(ctx, dE):
+        A, W = ctx.saved_tensors
+        b, (F, N) = A.shape[0], W.shape
+        lib, dev = _lib.load(), A.device
+        dE = dE.contiguous()
+        st = _lib.current_stream(dev)
+        dA = dW = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(F, N, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.sgnn_batch_project_workspace_bytes(b, F, N, 1) // 4, dtype=torch.float32, device=dev)
+            _lib.check(lib.sgnn_batch_project_grad_f32(b, F, _lib.ptr(A), F, b, None, ctx.slope, _lib.ptr(dE), N, N,
+                                                       _lib.ptr(dW), N, _lib.ptr(ws), ws.numel() * 4, st))
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty(b, F, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.sgnn_batch_project_workspace_bytes(b, F, N, 2) // 4, dtype=torch.float32, device=dev)
+            _lib.check(lib.sgnn_batch_project_input_grad_f32(b, F, N, _lib.ptr(dE), N, _lib.ptr(W), W.stride(0),
+                                                             _lib.ptr(A), F, ctx.slope, _lib.ptr(dA), F, _lib.ptr(ws),
+                                                             ws.numel() * 4, st))
+        return dA, dW, None
+
+
 def _activation_slope(act):
     """The slope s of ``act(x) = x if x > 0 else s * x`` for the activations that have that
     form (linear, relu, leaky_relu), else None."""
@@ -348,6 +388,8 @@ class _Layer(torch.nn.Module):
         if (not self._u_identity and X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1
                 and not X.requires_grad and self.U.is_contiguous() and idx.numel() > 0):
             XU = _BatchProject.apply(X, idx, self.U, 1.0)          # gather folded into X[idx] . U and into dU
+            if slope is not None and self.W.is_contiguous():
+                return self.activation(_DenseProject.apply(XU, self.W, slope))
             return self.activation(self.inner_activation(XU).matmul(self.W))
         return self(X[idx])
 

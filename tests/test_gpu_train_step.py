@@ -230,3 +230,25 @@ def test_label_head_matches_torch(gpu_device, B, D, C, indexed):
     a = _head_cross_entropy(wide, Ww, labels, idx)
     b = Fn.cross_entropy(wide.matmul(Ww), labels[idx] if indexed else labels)
     assert abs(a.item() - b.item()) <= 1e-5 * max(1.0, abs(b.item()))
+
+
+@pytest.mark.parametrize("b,F,N", [(512, 602, 128), (512, 128, 64), (1, 1, 1), (33, 65, 31), (100, 40, 200), (70, 300, 20)])
+@pytest.mark.parametrize("slope", [1.0, 0.0, 0.2])
+def test_dense_projection_matches_torch(gpu_device, b, F, N, slope):
+    from sgnn_amd.stacked import _DenseProject
+    g = torch.Generator(device=gpu_device); g.manual_seed(7 * b + F + N)
+    A = torch.randn(b, F, device=gpu_device, generator=g).requires_grad_()
+    W = (torch.randn(F, N, device=gpu_device, generator=g) * 0.1).requires_grad_()
+    A2, W2 = A.detach().clone().double().requires_grad_(), W.detach().clone().double().requires_grad_()
+    dE = torch.randn(b, N, device=gpu_device, generator=g)
+    E = _DenseProject.apply(A, W, slope)
+    ref = Fn.leaky_relu(A2, slope).matmul(W2)
+    E.backward(dE)
+    ref.backward(dE.double())
+    H = Fn.leaky_relu(A2.detach(), slope).abs()
+    scale = H.matmul(W2.detach().abs()).clamp_min(1e-30)
+    assert ((E.double() - ref).abs() / scale).max().item() <= 1e-5
+    gW = H.t().matmul(dE.double().abs()).clamp_min(1e-30)
+    assert ((W.grad.double() - W2.grad).abs() / gW).max().item() <= 1e-5
+    gA = dE.double().abs().matmul(W2.detach().abs().t()).clamp_min(1e-30)
+    assert ((A.grad.double() - A2.grad).abs() / gA).max().item() <= 1e-5
