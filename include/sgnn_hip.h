@@ -274,8 +274,8 @@ int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, const int64_t* map
  *   retain = 1 - max(random symmetric ignore mask without diagonal, overlook block)
  *            (model/SGNN.py:157-159, 172-175, 209-226): a pair is ignored with
  *            probability 2*mask_rate - mask_rate^2 (either of the reference's two draws),
- *            drawn from `state` = uint64[3] {seed, counter, 0} (counter advanced on the
- *            stream, as in sgnn_batch_indices); the overlook matrix is its unit diagonal
+ *            drawn from `state` = uint64[3] {seed, counter, 0} (read only here: the counter is
+ *            advanced by the sgnn_gae_loss_grad_f32 call that completes the pair); the overlook matrix is its unit diagonal
  *            plus, optionally, the pattern of a second CSR (overlook_rowptr/colidx, sorted
  *            columns; both NULL = diagonal only),
  *   row_pos[i] = sum_j target*retain, row_ret[i] = sum_j retain.
@@ -284,6 +284,8 @@ int sgnn_batch_indices(int64_t n, int64_t b, uint64_t* state, const int64_t* map
  *   loss = mean(-ratio * target * log(max(P, 1e-6)) * retain) [if num_pos > 0]
  *        + mean(-(1 - target) * log(max(1 - P, 1e-6)) * retain),
  *   P = sigmoid(clamp(S, -40, 40)), num_pos = sum(row_pos), ratio = sum(row_ret)/num_pos - 1.
+ *   `state` (may be NULL): the state passed to sgnn_gae_targets_f32; its counter is advanced
+ *   here, so that the next pair (or the next replay of a captured pair) draws another mask.
  * The caller completes dZ = (G + G^T) Z.
  */
 int sgnn_gae_targets_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
@@ -291,7 +293,8 @@ int sgnn_gae_targets_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, con
                          int64_t b, const int64_t* idx, float mask_rate, uint64_t* state,
                          float* target, float* retain, float* row_pos, float* row_ret, void* stream);
 int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* target, const float* retain,
-                           const float* row_pos, const float* row_ret, float* G, float* row_loss, void* stream);
+                           const float* row_pos, const float* row_ret, float* G, float* row_loss,
+                           uint64_t* state, void* stream);
 
 /*
  * The dense tail of one optimiser iteration of a decoupled layer, one launch each.
@@ -303,8 +306,9 @@ int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* 
  *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = steps so far + 1.
  *   params / grads / exp_avg / exp_avg_sq / sizes / weight_decay are HOST arrays of `count`
  *   entries (device pointers, element counts, per-tensor penalties; a NULL penalty array = 0).
- *   `state` is uint64[2] in device memory, zero before the first step: {steps taken,
- *   internal}; the launch advances it, so a captured HIP graph keeps counting on replay.
+ *   `state` is uint64[SGNN_ADAM_STATE_WORDS] in device memory, all zero before the first
+ *   step: word 0 = steps taken, the rest internal (left zero); the launch advances it, so a
+ *   captured HIP graph keeps counting on replay.
  *   With weight_decay = 2 * lam on W, b and U this also covers the ridge penalty of
  *   model/SGNN.py:89-92, with l1_decay = lam the LASSO penalty of model/SGNN.py:93-96
  *   (their gradients; the penalty's value is not added to any reported loss).
@@ -321,6 +325,7 @@ int sgnn_gae_loss_grad_f32(int64_t b, const float* S, int64_t lds, const float* 
  * irrelevant): the per-row terms go through it and are added in a fixed order by a second
  * small launch, so the loss value does not depend on scheduling.
  */
+#define SGNN_ADAM_STATE_WORDS 1026
 int sgnn_adam_step_f32(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* sizes, const float* weight_decay,
                        const float* l1_decay, float lr, float beta1, float beta2, float eps, uint64_t* state,

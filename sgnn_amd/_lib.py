@@ -20,6 +20,7 @@ DROP_ZEROS = 2
 SYMMETRIZE = 4
 CLAMP_ONE = 8
 SAMPLE_SKIP_SELF = 1
+ADAM_STATE_WORDS = 1026
 LOOPS_NONE, LOOPS_ADD, LOOPS_REMAINING = 0, 1, 2
 EPI_SCALE_ROW, EPI_SCALE_ROW2 = 0, 1
 
@@ -59,7 +60,7 @@ SIGNATURES = {
                                      c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
     "sgnn_gae_loss_grad_f32": (c_int, [c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p]),
     "sgnn_batch_indices": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgnn_adam_step_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    c_float, c_float, c_float, c_void_p, c_void_p]),

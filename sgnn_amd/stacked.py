@@ -113,7 +113,7 @@ class _FusedAdam:
         self.lr, self.betas, self.eps, self.device = float(lr), betas, float(eps), device
         self.exp_avg = [torch.zeros_like(e[0]) for e in self.entries]
         self.exp_avg_sq = [torch.zeros_like(e[0]) for e in self.entries]
-        self.state = torch.zeros(2, dtype=torch.int64, device=device)
+        self.state = torch.zeros(_lib.ADAM_STATE_WORDS, dtype=torch.int64, device=device)
 
     def zero_grad(self, set_to_none=True):
         for q, _, _ in self.entries:
@@ -568,7 +568,7 @@ class _FusedReconstruction(torch.autograd.Function):
         S = Zc.matmul(Zc.t())
         G = torch.empty((b, b), dtype=torch.float32, device=dev)
         _lib.check(lib.sgnn_gae_loss_grad_f32(b, _lib.ptr(S), b, _lib.ptr(target), _lib.ptr(retain), _lib.ptr(sums[0]),
-                                              _lib.ptr(sums[1]), _lib.ptr(G), _lib.ptr(sums[2]), st))
+                                              _lib.ptr(sums[1]), _lib.ptr(G), _lib.ptr(sums[2]), _lib.ptr(state), st))
         loss = torch.empty((), dtype=torch.float32, device=dev)
         _lib.check(lib.sgnn_sum_f32(b, _lib.ptr(sums[2]), 1.0, _lib.ptr(loss), st))
         ctx.save_for_backward(Zc, G)

@@ -36,7 +36,7 @@ def test_fused_adam_follows_torch_adam(gpu_device, l1):
             b.grad = grad.clone() + (l1 * torch.sign(b.detach()) if k < split else 0)
         fused.step()
         stock.step()
-    assert int(fused.state[0].item()) == 40 and int(fused.state[1].item()) == 0
+    assert int(fused.state[0].item()) == 40 and int(fused.state[1:].abs().sum().item()) == 0
     for a, b in zip(mine, ref):
         if a.shape == (3,):
             continue                                  # stepped on its own schedule above: torch keeps a per-tensor count
@@ -132,7 +132,7 @@ def test_identity_projection_is_skipped_exactly(gpu_device):
 def test_train_step_entry_points_reject_bad_arguments(gpu_device):
     from sgnn_amd import _lib
     lib = _lib.load()
-    state = torch.zeros(2, dtype=torch.int64, device=gpu_device)
+    state = torch.zeros(_lib.ADAM_STATE_WORDS, dtype=torch.int64, device=gpu_device)
     st = _lib.current_stream(gpu_device)
     arr = (ctypes.c_void_p * 17)()
     sizes = (ctypes.c_int64 * 17)()

@@ -71,7 +71,7 @@ def test_argument_errors_are_reported_not_crashes():
                                     None, None, None, None, None) == -1 and b"mask_rate" in lib.sgnn_last_error()
     assert lib.sgnn_gae_targets_f32(4, 4, None, None, None, None, None, 0, None, 0.2, None,
                                     None, None, None, None, None) == 0
-    assert lib.sgnn_gae_loss_grad_f32(3, None, 2, None, None, None, None, None, None, None) == -1
+    assert lib.sgnn_gae_loss_grad_f32(3, None, 2, None, None, None, None, None, None, None, None) == -1
     assert lib.sgnn_rowgroup_weights_bytes(1000, 16) >= 1000 * 16 * 4
     assert lib.sgnn_rowgroup_weights_bytes(1000, 5) == 0
     assert lib.sgnn_rowgroup_weights(4, 4, None, None, None, 16, None, 0, 4, None, 0, None) == -1
