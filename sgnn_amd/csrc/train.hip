@@ -48,9 +48,13 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a, float lr, float beta1,
   __shared__ float s_wd[kMaxAdamTensors];
   __shared__ float s_l1[kMaxAdamTensors];
   const unsigned long long step = state[0] + 1ull;
-  if (threadIdx.x == 0) {
-    corr[0] = float(1.0 - pow(double(beta1), double(step)));
-    corr[1] = float(1.0 - pow(double(beta2), double(step)));
+  if (threadIdx.x < 2) {        // beta^step by repeated squaring in double: ~40 multiplications, no libm call
+    double base = threadIdx.x == 0 ? double(beta1) : double(beta2), r = 1.0;
+    for (unsigned long long e = step; e != 0; e >>= 1) {
+      if (e & 1ull) r *= base;
+      base *= base;
+    }
+    corr[threadIdx.x] = float(1.0 - r);
   }
 #pragma unroll
   for (int k = 0; k < kMaxAdamTensors; ++k)      // constant indices: the table never leaves registers
@@ -62,24 +66,43 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a, float lr, float beta1,
   __syncthreads();
   const float step_size = lr / corr[0];
   const float inv_sqrt_c2 = 1.f / sqrtf(corr[1]);
-#pragma unroll 4
-  for (int e = 0; e < kAdamPerThread; ++e) {
-    const int64_t i = int64_t(blockIdx.x) * (256 * kAdamPerThread) + e * 256 + threadIdx.x;
-    if (i >= total) break;
-    int k = 0;
-    while (i >= s_end[k]) ++k;
-    const int64_t j = i - (k ? s_end[k - 1] : 0);
-    float p = s_p[k][j];
+  const auto update = [&](float* __restrict__ P, const float* __restrict__ G, float* __restrict__ Mm,
+                          float* __restrict__ V, float wd, float l1, int64_t j) {
+    float p = P[j];
     const float sign = p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f);
-    const float g = s_g[k][j] + s_wd[k] * p + s_l1[k] * sign;   // penalties enter through their gradients
-    float m = s_m[k][j], v = s_v[k][j];
+    const float g = G[j] + wd * p + l1 * sign;    // penalties enter through their gradients
+    float m = Mm[j], v = V[j];
     m = m + (1.f - beta1) * (g - m);
     v = beta2 * v + (1.f - beta2) * g * g;
     const float denom = sqrtf(v) * inv_sqrt_c2 + eps;
     p -= step_size * (m / denom);
-    s_p[k][j] = p;
-    s_m[k][j] = m;
-    s_v[k][j] = v;
+    P[j] = p;
+    Mm[j] = m;
+    V[j] = v;
+  };
+  const int64_t first = int64_t(blockIdx.x) * (256 * kAdamPerThread);
+  const int64_t last = first + 256 * kAdamPerThread - 1 < total ? first + 256 * kAdamPerThread - 1 : total - 1;
+  int kf = 0, kl = 0;                             // tensors of the workgroup's first and last element
+  while (first >= s_end[kf]) ++kf;
+  while (last >= s_end[kl]) ++kl;
+  if (kf == kl) {                                 // the usual case: one tensor, uniform pointers, no per-element search
+    const int64_t base = kf ? s_end[kf - 1] : 0;
+    float* P = s_p[kf]; const float* G = s_g[kf]; float* Mm = s_m[kf]; float* V = s_v[kf];
+    const float wd = s_wd[kf], l1 = s_l1[kf];
+#pragma unroll
+    for (int e = 0; e < kAdamPerThread; ++e) {
+      const int64_t i = first + e * 256 + threadIdx.x;
+      if (i <= last) update(P, G, Mm, V, wd, l1, i - base);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < kAdamPerThread; ++e) {
+      const int64_t i = first + e * 256 + threadIdx.x;
+      if (i > last) break;
+      int k = kf;
+      while (i >= s_end[k]) ++k;
+      update(s_p[k], s_g[k], s_m[k], s_v[k], s_wd[k], s_l1[k], i - (k ? s_end[k - 1] : 0));
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {       // no data passes between workgroups, so the counts need no fence
