@@ -573,6 +573,9 @@ class _FusedReconstruction(torch.autograd.Function):
         _lib.check(lib.sgnn_sum_f32(b, _lib.ptr(sums[2]), 1.0, _lib.ptr(loss), st))
         ctx.save_for_backward(Zc, G)
         ctx.unit = unit
+        # S = Z Z^T, the mask and (for an undirected graph) the target are symmetric, hence so is
+        # G: (G + G^T) Z = 2 G Z, one product without the transposed sum
+        ctx.sym = bool(adjacency.symmetric and (overlook is None or overlook.symmetric))
         ctx.mark_non_differentiable(target, retain)
         ctx.set_materialize_grads(False)          # no b x b zero blocks for the two auxiliary outputs
         return loss, target, retain
@@ -582,7 +585,7 @@ class _FusedReconstruction(torch.autograd.Function):
         if grad_loss is None:
             return (None,) * 7
         Z, G = ctx.saved_tensors
-        dZ = (G + G.t()).matmul(Z)
+        dZ = torch.addmm(Z, G, Z, beta=0.0, alpha=2.0) if ctx.sym else (G + G.t()).matmul(Z)
         return (dZ if ctx.unit else grad_loss * dZ), None, None, None, None, None, None
 
 

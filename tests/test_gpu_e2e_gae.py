@@ -142,6 +142,22 @@ def test_fused_reconstruction_matches_autograd(gpu_device):
         assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-7
         err = (got_grad - Z2.grad).norm() / Z2.grad.norm().clamp_min(1e-12)
         assert float(err) <= 1e-5, float(err)
+    # a directed graph: the target block is not symmetric and the general (G + G^T) Z route is taken
+    rngd = np.random.default_rng(5)
+    dadj = NormAdj.from_coo(rngd.integers(0, n, 40 * n), rngd.integers(0, n, 40 * n), None, n, gpu_device)
+    assert not dadj.symmetric
+    gen = torch.Generator().manual_seed(11)
+    idx = torch.randperm(n, generator=gen)[:192].to(gpu_device)
+    Z = (torch.randn(192, 24, generator=gen) * 0.8).to(gpu_device).requires_grad_(True)
+    state = torch.tensor([3, 0, 0], dtype=torch.int64, device=gpu_device)
+    loss, target, retain = _FusedReconstruction.apply(Z, dadj, None, idx, 0.25, state)
+    loss.backward()
+    assert not torch.equal(target, target.t())
+    Z2 = Z.detach().clone().requires_grad_(True)
+    ref = GAELayer.reconstruction_loss(torch.sigmoid(Z2.matmul(Z2.t()).clamp(-40.0, 40.0)), target, retain)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-7
+    assert float((Z.grad - Z2.grad).norm() / Z2.grad.norm()) <= 1e-5
     # same (seed, counter) -> same mask; next counter -> another one
     s1 = torch.tensor([1, 0, 0], dtype=torch.int64, device=gpu_device)
     s2 = torch.tensor([1, 0, 0], dtype=torch.int64, device=gpu_device)
