@@ -213,6 +213,15 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
                                                      float* __restrict__ retain, float* __restrict__ row_pos,
                                                      float* __restrict__ row_ret) {
   const int64_t i = blockIdx.x;
+  // this thread's columns of the block, fetched ahead of the chain idx[i] -> rowptr -> colidx
+  // below so that their latency hides behind it (the first kPre trips of the j loop)
+  constexpr int kPre = 4;
+  int64_t pre[kPre];
+#pragma unroll
+  for (int e = 0; e < kPre; ++e) {
+    const int64_t j = threadIdx.x + int64_t(e) * blockDim.x;
+    pre[e] = j < b ? idx[j] : -1;
+  }
   const int64_t node = idx[i];
   const bool ok = node >= 0 && node < n_rows;
   const int lo0 = ok ? rowptr[node] : 0, hi0 = ok ? rowptr[node + 1] : 0;
@@ -237,8 +246,16 @@ __global__ __launch_bounds__(256) void k_gae_targets(int64_t n_rows, const int* 
   const uint32_t k1 = mix32(uint32_t(seed >> 32) + mix32(uint32_t(counter >> 32) ^ 0x85ebca6bu));
   const uint32_t thresh = p_mask >= 1.f ? 0xffffffffu : uint32_t(double(p_mask) * 4294967296.0);
   float s_pos = 0.f, s_ret = 0.f;
-  for (int64_t j = threadIdx.x; j < b; j += blockDim.x) {
-    const int64_t want = idx[j];
+  int trip = 0;
+  for (int64_t j = threadIdx.x; j < b; j += blockDim.x, ++trip) {
+    int64_t want;
+    switch (trip) {                               // constant indices keep pre[] in registers
+      case 0: want = pre[0]; break;
+      case 1: want = pre[1]; break;
+      case 2: want = pre[2]; break;
+      case 3: want = pre[3]; break;
+      default: want = idx[j];
+    }
     const bool self = want == node;
     float a = 0.f;
     if (!self) {

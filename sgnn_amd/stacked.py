@@ -560,7 +560,8 @@ class _FusedReconstruction(torch.autograd.Function):
         sums = torch.empty((3, b), dtype=torch.float32, device=dev)          # row_pos, row_ret, row_loss
         st = _lib.current_stream(dev)
         _lib.check(lib.sgnn_gae_targets_f32(
-            adjacency.n, adjacency.nnz, _lib.ptr(adjacency.rowptr), _lib.ptr(adjacency.colidx), _lib.ptr(adjacency.vals),
+            adjacency.n, adjacency.nnz, _lib.ptr(adjacency.rowptr), _lib.ptr(adjacency.colidx),
+            None if adjacency.unit_weights else _lib.ptr(adjacency.vals),     # all 1: no value lookups
             None if overlook is None else _lib.ptr(overlook.rowptr),
             None if overlook is None else _lib.ptr(overlook.colidx),
             b, _lib.ptr(idx), float(mask_rate), _lib.ptr(state), _lib.ptr(target), _lib.ptr(retain),
