@@ -311,7 +311,10 @@ def main():
     copy_gbps = copy_ceiling(device) if (rank == 0 and world == 1) else None
     epoch = None
     if world == 1 and args.workload == "reddit" and args.epoch_iters > 0:   # outside the timed SpMM region
-        epoch = sgnn_epoch(adj, X, device, args.epoch_iters, args.seed)
+        try:
+            epoch = sgnn_epoch(adj, X, device, args.epoch_iters, args.seed)
+        except Exception as exc:                  # the SpMM line must come out whatever happens here
+            epoch = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         units = nnz * F * args.order                          # (E + n) . F per hop
