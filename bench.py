@@ -308,7 +308,12 @@ def main():
         wall = float(t.item())
     ev_ms = ev0.elapsed_time(ev1) / args.steps              # HIP events on the launch stream
 
-    copy_gbps = copy_ceiling(device) if (rank == 0 and world == 1) else None
+    copy_gbps = None
+    if rank == 0 and world == 1:
+        try:
+            copy_gbps = copy_ceiling(device)
+        except Exception as exc:
+            print(f"[bench] copy ceiling not measured: {exc}", file=sys.stderr, flush=True)
     epoch = None
     if world == 1 and args.workload == "reddit" and args.epoch_iters > 0:   # outside the timed SpMM region
         try:
@@ -369,7 +374,10 @@ def main():
         if epoch:
             out["sgnn_epoch"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in epoch.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, F, args.seed, device, args.cpu_sample_edges)
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, F, args.seed, device, args.cpu_sample_edges)
+            except Exception as exc:
+                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()
