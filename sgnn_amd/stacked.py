@@ -29,11 +29,20 @@ the reference:
 
 What differs, on purpose (these are the residency and launch-overhead items the
 reference leaves on the table): the Adam iterations of a layer run are captured once into
-a HIP graph and replayed (``_Layer._optimise``); features, targets and embeddings stay on the GPU instead of bouncing
-through host memory on every call (model/SGNN.py:404, 442-443), and ``A_hat^k X`` of a
-layer is computed once per distinct input instead of on every ``run`` — the first
-layer's input never changes, so 2*BP_count of its 2*BP_count+1 propagations
-disappear.
+a HIP graph and replayed (``_Layer._optimise``); features, targets and embeddings stay on
+the GPU instead of bouncing through host memory on every call (model/SGNN.py:404,
+442-443), and ``A_hat^k X`` of a layer is computed once per distinct input instead of on
+every ``run`` — the first layer's input never changes, so 2*BP_count of its 2*BP_count+1
+propagations disappear.
+
+An optimiser iteration itself runs on the library's own kernels where its shape allows:
+the batch projection with the row gather and the inner activation folded in
+(``_BatchProject``, ``_DenseProject``), the label head with its loss and gradients
+(``_HeadXent``), the target error (``_SqErr``), the reconstruction loss
+(``_FusedReconstruction``) and Adam with the ridge / LASSO penalty applied through the
+gradient (``_FusedAdam``); each has the stock torch operators as the route for shapes or
+dtypes it does not cover, and ``tests/test_gpu_train_step.py`` holds them to those
+operators.  The penalties' values are therefore not part of any loss value returned here.
 """
 from __future__ import annotations
 
