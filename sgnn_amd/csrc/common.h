@@ -62,6 +62,14 @@ struct Carver {
 
 constexpr int kWave = 64;
 
+// A buffer load's range check looks at voffset (+ the instruction offset) only.  Lanes
+// that must not touch memory get this voffset: it lies beyond every descriptor the
+// kernels build (those span less than kBigX bytes), so the load returns 0.
+constexpr int kOobVoffset = int(0xFFFFF000u);
+// Operands of at least this many bytes are addressed by re-basing the descriptor on
+// the fetched row instead of a 32-bit byte offset.
+constexpr int64_t kBigX = (int64_t(1) << 32) - 8192;
+
 // untyped raw buffer over [base, base + bytes): stride 0, range-checked
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, uint32_t bytes) {
   const uint64_t b = reinterpret_cast<uint64_t>(base);

@@ -403,6 +403,18 @@ struct Lay {
   static constexpr int kOff1 = C4 * 256 + C2 * 128;  // first feature of the 4-byte chunks
 };
 
+// Byte offset of a lane's piece of a fetched row.  The buffer load's range check sees
+// this voffset only (the row offset travels in soffset, which is not checked), so the
+// lanes of the row's LAST chunk whose first feature lies at or past F get an offset no
+// descriptor covers and read 0 without touching memory.  A lane that starts below F may
+// run up to 3 floats past it: those lie inside the row's stride (ldx is a multiple of
+// 4), which is why X must be readable for n_cols * ldx floats.
+template <bool LAST_KIND>
+__device__ __forceinline__ int rg_voff(const RgArgs& a, int c, int chunks, int feature) {
+  if (LAST_KIND && c == chunks - 1) return feature < a.F ? feature * 4 : kOobVoffset;
+  return feature * 4;
+}
+
 // Issue the fetches of UU consecutive merged columns (lanes k .. k+UU-1 of `cols`).
 // With weights (HASW) the R weights of each of the UU columns follow: they are stored
 // [merged column][row of the group], so one coalesced load by the first UU*R lanes brings
@@ -422,23 +434,23 @@ __device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t col
     if constexpr (BIGX) {   // X spans 4 GiB or more: re-base the descriptor on the fetched row
       rr = make_rsrc(a.X + int64_t(col) * a.ldx, uint32_t(a.F) * 4u);
     } else {
-      soff = col * a.row_bytes;
+      soff = int(uint32_t(col) * uint32_t(a.row_bytes));   // up to 4 GiB: unsigned
     }
 #pragma unroll
     for (int c = 0; c < C4; ++c) {
-      const f32x4 x = raw_buffer_load_f32x4(rr, lane * 16 + c * 1024, soff, 0);
+      const f32x4 x = raw_buffer_load_f32x4(rr, rg_voff<(C2 == 0 && C1 == 0)>(a, c, C4, lane * 4 + c * 256), soff, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) xv[u][4 * c + j] = x[j];
     }
 #pragma unroll
     for (int c = 0; c < C2; ++c) {
-      const f32x2 x = raw_buffer_load_f32x2(rr, lane * 8 + (L::kOff2 + c * 128) * 4, soff, 0);
+      const f32x2 x = raw_buffer_load_f32x2(rr, rg_voff<(C1 == 0)>(a, c, C2, lane * 2 + L::kOff2 + c * 128), soff, 0);
       xv[u][4 * C4 + 2 * c] = x[0];
       xv[u][4 * C4 + 2 * c + 1] = x[1];
     }
 #pragma unroll
     for (int c = 0; c < C1; ++c)
-      xv[u][4 * C4 + 2 * C2 + c] = raw_buffer_load_f32(rr, lane * 4 + (L::kOff1 + c * 64) * 4, soff, 0);
+      xv[u][4 * C4 + 2 * C2 + c] = raw_buffer_load_f32(rr, rg_voff<true>(a, c, C1, lane + L::kOff1 + c * 64), soff, 0);
   }
 }
 
@@ -678,7 +690,7 @@ int launch_rg(const RgArgs& a, hipStream_t st) {
   constexpr int U = NF <= 2 ? 8 : (NF <= 4 ? 4 : 2);
   constexpr int UW = U * R <= kWave ? U : kWave / R;   // with weights: a step's U*R weights in one load
   const dim3 grid(unsigned((a.items + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWave * kWavesPerBlock);
-  const bool bigx = a.x_bytes >= (int64_t(1) << 32);
+  const bool bigx = a.x_bytes >= kBigX;
   if (a.gw != nullptr) {
     if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, true, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, false, true>), grid, block, 0, st, a);
@@ -726,7 +738,9 @@ int64_t rg_slice_width(int64_t F) {
 // gather, and keep R = 8
 int rg_rows_for(int64_t F) {
   if (F < 33) return 0;
-  F = rg_slice_width(F);
+  const int64_t width = rg_slice_width(F);
+  if (F > width && F - (F - 1) / width * width < 33) return 0;   // last slice too narrow: plain CSR kernel
+  F = width;
   const Layout l = rg_layout(F);
   if (l.nf() > 10) return 0;   // cannot happen for a slice of at most 640 columns
   if (g_R_override == 8 || g_R_override == 16) return g_R_override;
@@ -928,14 +942,20 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   // one launch per feature slice (a single one up to 640 columns); the slices share the
   // partial-row workspace, which is safe because they run in order on one stream
   const int64_t width = rg_slice_width(F);
+  // every slice is checked before the first launch, so an unsupported width leaves Y untouched
   for (int64_t f0 = 0; f0 < F; f0 += width) {
     const int64_t w = F - f0 < width ? F - f0 : width;
     if (w < 33) return fail(SGNN_ERR_UNSUPPORTED, "feature slice too narrow for the row-group kernel");
+    if (rg_layout(w).nf() > 10) return fail(SGNN_ERR_UNSUPPORTED, "no row-group kernel for this (R, F)");
+  }
+  if (R != 8 && R != 16) return fail(SGNN_ERR_UNSUPPORTED, "no row-group kernel for this (R, F)");
+  for (int64_t f0 = 0; f0 < F; f0 += width) {
+    const int64_t w = F - f0 < width ? F - f0 : width;
     a.X = X + f0;
     a.Y = Y + f0;
     a.F = int32_t(w);
     a.x_bytes = ((n_cols - 1) * ldx + w) * 4;
-    a.row_bytes = a.x_bytes < (int64_t(1) << 32) ? int32_t(ldx * 4) : 0;
+    a.row_bytes = a.x_bytes < kBigX ? int32_t(ldx * 4) : 0;
     const uintptr_t py = reinterpret_cast<uintptr_t>(a.Y);
     a.y_vec = (py % 16 == 0 && ldy % 4 == 0) ? 4 : ((py % 8 == 0 && ldy % 2 == 0) ? 2 : 1);
     const int rc = dispatch_rg(a, R, rg_layout(w), st);

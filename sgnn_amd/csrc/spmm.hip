@@ -50,8 +50,10 @@ struct SpmmArgs {
 // addressed through a buffer descriptor over X with the row's byte offset in a
 // scalar register (soffset) and the lane's byte offset inside the row in one
 // loop-invariant VGPR: a row fetch costs no vector ALU work.  Buffer loads need
-// only dword alignment, and lanes past the end of X read 0 (range check); lanes
-// past the end of a row read the next row's head, which is never stored.
+// only dword alignment.  The hardware range check compares the lane's voffset alone
+// with the descriptor's size (soffset is not part of it), so a lane whose features
+// lie past the end of the row is given a voffset beyond any descriptor
+// (kOobVoffset): it reads 0 and touches no memory, also on the last row of X.
 // The loop is software-pipelined: the ids of the next U entries are requested
 // while the U*C vector loads of the current ones are in flight.  Entries are
 // added in column order.
@@ -72,7 +74,7 @@ __device__ __forceinline__ void uniform_step(const SpmmArgs& a, i32x4 rsrc, int3
 #pragma unroll
       for (int c = 0; c < C; ++c) buffer_load_vec<V>(rr, boff[c], 0, xv[u][c]);
     } else {
-      const int soff = col * a.row_bytes;
+      const int soff = int(uint32_t(col) * uint32_t(a.row_bytes));   // up to 4 GiB: unsigned
 #pragma unroll
       for (int c = 0; c < C; ++c) buffer_load_vec<V>(rsrc, boff[c], soff, xv[u][c]);
     }
@@ -201,8 +203,11 @@ __device__ __forceinline__ void reduce_entries(const SpmmArgs& a, int32_t e0, in
     const int lane = threadIdx.x & (kWave - 1);
     int boff[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) boff[c] = (f0 + (c * kWave + lane) * V) * 4;
-    if (a.x_bytes < (int64_t(1) << 32)) uniform_reduce<V, C, U, false>(a, e0, e1, boff, acc);
+    for (int c = 0; c < C; ++c) {
+      const int f = f0 + (c * kWave + lane) * V;   // V divides F: a lane is inside the row or past it
+      boff[c] = f < a.F ? f * 4 : kOobVoffset;
+    }
+    if (a.x_bytes < kBigX) uniform_reduce<V, C, U, false>(a, e0, e1, boff, acc);
     else uniform_reduce<V, C, U, true>(a, e0, e1, boff, acc);
   } else {
     static_assert(LPR == kWave || (V == 1 && C == 1), "the split layout is scalar");
@@ -435,7 +440,7 @@ int spmm_impl(int64_t n_rows, int64_t n_cols, int64_t F, const int32_t* rowptr, 
   a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.dinv_row = dinv_row; a.dinv_col = dinv_col;
   a.X = X; a.Y = Y; a.ldx = ldx; a.ldy = ldy; a.n_rows = int32_t(n_rows); a.F = int32_t(F); a.epilogue = epilogue;
   a.x_bytes = ((n_cols - 1) * ldx + F) * 4;
-  a.row_bytes = a.x_bytes < (int64_t(1) << 32) ? int32_t(ldx * 4) : 0;
+  a.row_bytes = a.x_bytes < kBigX ? int32_t(ldx * 4) : 0;
   const uintptr_t py = reinterpret_cast<uintptr_t>(Y);
   a.y_vec = (py % 16 == 0 && ldy % 4 == 0) ? 4 : ((py % 8 == 0 && ldy % 2 == 0) ? 2 : 1);
   SpmmWs w = carve_spmm(workspace, nnz_bound, F);

@@ -553,15 +553,15 @@ int launch_project(int64_t M, int64_t N, int64_t K, int64_t n_rows, const float*
   using sgnn::fail;
   const ProjectGrid g = project_grid(M, N, K);
   const bool staged = g.splits > 1 || pre != nullptr;        // the derivative mask is applied by the summing launch
-  if (staged) {
-    if (ws_bytes < size_t(g.splits * g.tiles_m * g.tiles_n) * 1024 * sizeof(float4))
-      return fail(SGNN_ERR_WORKSPACE, "projection workspace too small");
-    if (!ws) return fail(SGNN_ERR_INVALID, "null pointer");
-    if (g.splits > 65535) return fail(SGNN_ERR_INVALID, "dimension too large for one launch");
-  }
-  hipStream_t st = static_cast<hipStream_t>(stream);
   // with a single chunk and a mask the partial path is forced by a grid of depth 2 whose second chunk is empty
   const unsigned depth = unsigned(staged && g.splits == 1 ? 2 : g.splits);
+  if (staged) {
+    if (ws_bytes < size_t(depth) * size_t(g.tiles_m * g.tiles_n) * 1024 * sizeof(float4))
+      return fail(SGNN_ERR_WORKSPACE, "projection workspace too small");
+    if (!ws) return fail(SGNN_ERR_INVALID, "null pointer");
+    if (depth > 65535) return fail(SGNN_ERR_INVALID, "dimension too large for one launch");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(unsigned(g.tiles_n), unsigned(g.tiles_m), depth);
   hipLaunchKernelGGL((k_batch_project<GRAD, TRANSB>), grid, dim3(256), 0, st, M, N, K, n_rows, X, ldx, idx, slope, Bm,
                      ldb, C, ldc, static_cast<float4*>(ws));

@@ -45,18 +45,23 @@ class _GraphConvBase(nn.Module):
         self.add_self_loops = add_self_loops
         self.cached = cached
         self._adj = None
-        self._adj_key = None
+        self._adj_src = None
 
     def _norm_adj(self, x, edge_index, edge_weight):
         # the normalised adjacency depends only on the graph: rebuild it when the
         # edge tensors change, not on every forward (torch_geometric with
-        # cached=False redoes gcn_norm per call; the result is the same)
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
-               None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version), x.shape[0])
-        if self._adj is None or key != self._adj_key:
+        # cached=False redoes gcn_norm per call; the result is the same).  The key is
+        # the tensor objects themselves, kept alive here so that their storage cannot be
+        # freed and handed to a different graph, plus their in-place version counters.
+        src = self._adj_src
+        same = (self._adj is not None and src is not None and src[0] is edge_index and src[1] is edge_weight
+                and src[2] == edge_index._version
+                and src[3] == (None if edge_weight is None else edge_weight._version) and src[4] == x.shape[0])
+        if not same:
             self._adj = NormAdj.from_edge_index(edge_index, x.shape[0], device=x.device,
                                                 edge_weight=edge_weight, add_self_loops=self.add_self_loops)
-            self._adj_key = key
+            self._adj_src = (edge_index, edge_weight, edge_index._version,
+                             None if edge_weight is None else edge_weight._version, x.shape[0])
         return self._adj
 
 

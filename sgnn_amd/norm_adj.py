@@ -73,7 +73,10 @@ class NormAdj:
     def __init__(self, n, rowptr, colidx, vals, deg, dinv, unit_weights=False, symmetric=None,
                  w_off=None, corr=None):
         self.n = int(n)
-        self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
+        self.rowptr, self.colidx = rowptr, colidx
+        # all-ones values are not kept: no kernel reads them (NULL = 1.0 throughout the C ABI)
+        # and on the Reddit shape they would hold 0.46 GB; `vals` rebuilds them on request
+        self._vals = None if unit_weights else vals
         self.deg, self.dinv = deg, dinv
         self.nnz = int(colidx.numel())
         self.unit_weights = bool(unit_weights)
@@ -87,6 +90,13 @@ class NormAdj:
         self._ws = {}
         self._plans = {}                  # R -> row-group plan (built on first use)
         self.use_rowgroup = True          # uniform-weight graphs, supported widths: see _rowgroup_plan
+
+    @property
+    def vals(self):
+        """Stored values, fp32[nnz] (for a unit-weight graph a fresh tensor of ones)."""
+        if self._vals is None:
+            return torch.ones(self.nnz, dtype=torch.float32, device=self.device)
+        return self._vals
 
     # the reference's callers only ever look at .shape[0] of the adjacency handle
     # (model/SGNN.py:33)
@@ -143,9 +153,13 @@ class NormAdj:
             del ws
             if total < 0:
                 raise ValueError(f"adjacency indices out of range for a {n} x {n} matrix")
-            colidx = colidx[:total].clone()
-            vals = vals[:total].clone()
+            # the output buffers were sized for the worst case (no duplicates); copy the used
+            # part out only when that frees a worthwhile amount of memory
+            compact = (cap - total) * 16 > cap
+            colidx = colidx[:total].clone() if compact else colidx[:total]
+            vals = vals[:total]
             unit, w_off, corr = weight_structure(n, rowptr, colidx, vals)
+            vals = None if unit else (vals.clone() if compact else vals)
         return cls(n, rowptr, colidx, vals, deg, dinv, unit_weights=unit, w_off=w_off, corr=corr)
 
     @classmethod
@@ -359,7 +373,7 @@ class NormAdj:
         elif out.shape != (b, b) or out.dtype != torch.float32 or out.device != self.device or out.stride(1) != 1:
             raise ValueError("out must be a [b, b] fp32 tensor with unit column stride on the adjacency's device")
         _lib.check(_lib.load().sgnn_sample_block_f32(
-            self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), _lib.ptr(self.vals), b, _lib.ptr(idx),
+            self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), _lib.ptr(self._vals), b, _lib.ptr(idx),
             _lib.SAMPLE_SKIP_SELF if skip_self else 0, _lib.ptr(out), out.stride(0) if b > 1 else b,
             _lib.current_stream(self.device)))
         return out
@@ -373,16 +387,17 @@ class NormAdj:
         with torch.cuda.device(self.device):
             t_rowptr = torch.empty_like(self.rowptr)
             t_colidx = torch.empty_like(self.colidx)
-            t_vals = torch.empty_like(self.vals)
+            vals = self.vals
+            t_vals = torch.empty_like(vals)
             nbytes = lib.sgnn_transpose_workspace_bytes(self.n, self.nnz)
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
             _lib.check(lib.sgnn_csr_transpose(
-                self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), _lib.ptr(self.vals),
+                self.n, self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx), _lib.ptr(vals),
                 _lib.ptr(t_rowptr), _lib.ptr(t_colidx), _lib.ptr(t_vals), _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(self.device)))
             same = bool(torch.equal(t_rowptr, self.rowptr) and torch.equal(t_colidx, self.colidx)
-                        and torch.equal(t_vals, self.vals))
-            del ws
+                        and torch.equal(t_vals, vals))
+            del ws, vals
         self._symmetric = same
         if same:
             self._transposed = self

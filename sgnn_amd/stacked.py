@@ -511,6 +511,20 @@ class _Layer(torch.nn.Module):
         return embedding
 
 
+def _mask_to_rows(mask, device):
+    """Node ids a training mask selects.  The reference fancy-indexes with the mask
+    (model/SGNN.py:412-415), which takes a boolean mask (Planetoid loaders) as well as an
+    index array (data_loader.py:133 passes ``train_index`` for the OGB graphs)."""
+    mask = torch.as_tensor(mask).to(device)
+    if mask.dtype in (torch.bool, torch.uint8):          # torch indexes with a byte tensor as with a mask
+        return torch.nonzero(mask).squeeze(1)
+    if mask.dtype in (torch.int64, torch.int32, torch.int16, torch.int8):
+        if mask.dim() != 1:
+            raise ValueError("an index-array mask must be 1-D")
+        return mask.long().contiguous()
+    raise TypeError(f"training mask must be boolean or an integer index array, got {mask.dtype}")
+
+
 class EmbeddingLayer(_Layer):
     """One decoupled layer with a label head (SingleLayerEmbeddingGCN, model/SGNN.py:357-467)."""
 
@@ -525,7 +539,7 @@ class EmbeddingLayer(_Layer):
             # The reference samples rows of processed_X[mask] (model/SGNN.py:412-421); here the
             # drawn positions are mapped to node ids instead, so every batch reads PX, the labels
             # and the target directly and no masked copies are made.
-            train_rows = torch.nonzero(self.train_mask.to(self.device)).squeeze(1)
+            train_rows = _mask_to_rows(self.train_mask, self.device)
             n_train, n_all = train_rows.numel(), PX.shape[0]
             b1, b2 = min(self.batch_size, n_train), min(self.batch_size, n_all)
 

@@ -46,3 +46,30 @@ def test_stacked_sgnn_matches_reference_accuracy(gpu_device):
         assert model.gnns[0]._cache_in is model.content
     assert abs(np.mean(accs) - ref_acc) <= 0.03, (accs, ref_acc)
     assert min(agree) >= 0.93, agree
+
+
+def test_index_array_training_mask_draws_only_those_nodes(gpu_device):
+    """data_loader.py:133 hands an index array as train_mask for the OGB graphs; batches
+    must be drawn from exactly those node ids (model/SGNN.py:412-421)."""
+    from sgnn_amd import NormAdj
+    from sgnn_amd.stacked import EmbeddingLayer, LayerParam, _mask_to_rows, get_activation
+    n = 400
+    rng = np.random.default_rng(0)
+    r = rng.integers(0, n, 3000)
+    c = rng.integers(0, n, 3000)
+    adj = NormAdj.from_coo(np.concatenate((r, c)), np.concatenate((c, r)), None, n, gpu_device, strip_diag=True,
+                           clamp_one=True)
+    ids = torch.from_numpy(rng.choice(n, 37, replace=False))
+    labels = torch.from_numpy(rng.integers(0, 3, n)).to(gpu_device)
+    p = LayerParam(8, inner_act=get_activation("relu"), act=get_activation("linear"), gnn_type=LayerParam.EGCN,
+                   learning_rate=1e-3, max_iter=4, lam=1e-6, batch_size=16)
+    layer = EmbeddingLayer(adj, labels, ids, 12, 8, 3, p, gpu_device)
+    rows = _mask_to_rows(layer.train_mask, gpu_device)
+    assert sorted(rows.tolist()) == sorted(ids.tolist())
+    seen = set()
+    for _ in range(40):
+        seen.update(layer._batch(rows.numel(), row_map=rows).tolist())
+    assert seen <= set(ids.tolist()) and len(seen) == 37
+    X = torch.randn(n, 12, device=gpu_device)
+    out = layer.run(X)                       # trains on the 37 listed nodes without error
+    assert out.shape == (n, 8) and bool(torch.isfinite(out).all())

@@ -158,6 +158,14 @@ def test_train_step_entry_points_reject_bad_arguments(gpu_device):
     assert lib.sgnn_batch_project_workspace_bytes(512, 602, 128, 0) == 19 * 8 * 2 * 16384
     assert lib.sgnn_batch_project_f32(8, 64, _lib.ptr(z), 64, 4, _lib.ptr(lab), 0.2, _lib.ptr(z), 4, 4, _lib.ptr(z), 4,
                                       None, 0, st) != 0                                     # two chunks, no workspace
+    # one chunk (N <= 32) with a derivative mask still runs at depth 2: half the workspace is refused
+    need = lib.sgnn_batch_project_workspace_bytes(4, 4, 4, 2)
+    assert need == 2 * 16384
+    big = torch.zeros(need // 4, device=gpu_device)
+    assert lib.sgnn_batch_project_input_grad_f32(4, 4, 4, _lib.ptr(z), 4, _lib.ptr(z), 4, _lib.ptr(z), 4, 0.2,
+                                                 _lib.ptr(z), 4, _lib.ptr(big), need // 2, st) != 0
+    assert lib.sgnn_batch_project_input_grad_f32(4, 4, 4, _lib.ptr(z), 4, _lib.ptr(z), 4, _lib.ptr(z), 4, 0.2,
+                                                 _lib.ptr(z), 4, _lib.ptr(big), need, st) == 0
     torch.cuda.synchronize()
     assert int(state[0].item()) == 0
 
