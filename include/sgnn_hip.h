@@ -144,6 +144,25 @@ int sgnn_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F,
                       int epilogue, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * sgnn_spmm_csr_f32 for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments without
+ * the workspace, same kernels, same results bit for bit.  It has no counterpart in the
+ * reference.  The scratch (segment lists and partial sums of rows longer than 1024
+ * entries) lives in a 32 MiB device array inside the library, one copy per GPU, held
+ * until the process ends; the call neither allocates nor frees anything and returns
+ * SGNN_ERR_WORKSPACE when sgnn_spmm_workspace_bytes(n_rows, nnz, F) exceeds 32 MiB
+ * (about nnz * F <= 4e9).  The device the kernels run on must be the current device.
+ * The first call on a device looks the array's address up (make it outside graph capture).
+ * All calls on one GPU share the array: calls that overlap in time on one GPU (two
+ * streams, two host threads) race; calls on one stream are ordered and safe.
+ */
+int sgnn_spmm_csr_noalloc_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F,
+                              const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                              const float* dinv_row, const float* dinv_col,
+                              const float* X, int64_t ldx, float* Y, int64_t ldy,
+                              int epilogue, void* stream);
+
+/*
  * Y = A_hat^K . X for a square matrix: K hops of the kernel above with the
  * normalisation between hops folded into the epilogue (SGNN_EPI_SCALE_ROW2), so
  * no separate scaling pass touches the intermediates.  tmp is [n, F] fp32

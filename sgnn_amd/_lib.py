@@ -40,6 +40,8 @@ SIGNATURES = {
     "sgnn_spmm_csr_f32": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_size_t,
                                   c_void_p]),
+    "sgnn_spmm_csr_noalloc_f32": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "sgnn_spmm_chain_f32": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sgnn_rowgroup_config": (c_int, [c_int64]),

@@ -10,6 +10,7 @@
 // wavefront owns a 10^5-entry hub.
 #include "common.h"
 
+#include <atomic>
 #include <cstring>
 
 namespace {
@@ -454,6 +455,17 @@ int spmm_impl(int64_t n_rows, int64_t n_cols, int64_t F, const int32_t* rowptr, 
   return dispatch_spmm(a, st);
 }
 
+// ---- scratch for the entry point that allocates nothing --------------------------
+// sgnn_spmm_csr_noalloc_f32 keeps the long-row scratch of the SpMM (segment lists and
+// partial rows) in this array instead of a caller-provided workspace.  Every GPU the
+// library runs on holds its own copy, at its own address, until the process ends.
+// The array's name is a host-side stand-in for those copies, not a device address:
+// host code uses the pointer hipGetSymbolAddress returns for the current device.
+constexpr size_t kScratchBytes = size_t(32) << 20;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+std::atomic<void*> g_scratch_ptr[kMaxDevices];
+
 }  // namespace
 
 namespace sgnn {
@@ -494,6 +506,31 @@ int sgnn_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, co
   if (nnz < 0) return fail(SGNN_ERR_INVALID, "negative nnz");
   return spmm_impl(n_rows, n_cols, F, rowptr, colidx, vals, dinv_row, dinv_col, X, ldx, Y, ldy, epilogue, nnz,
                    workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int sgnn_spmm_csr_noalloc_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, const int32_t* rowptr,
+                              const int32_t* colidx, const float* vals, const float* dinv_row,
+                              const float* dinv_col, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                              int epilogue, void* stream) {
+  if (nnz < 0 || F < 0) return fail(SGNN_ERR_INVALID, "negative size");
+  const size_t need = carve_spmm(nullptr, nnz, F).total;
+  if (need > kScratchBytes)
+    return fail(SGNN_ERR_WORKSPACE, "problem too large for the built-in scratch: needs " + std::to_string(need) +
+                                        " bytes, the library holds " + std::to_string(kScratchBytes) +
+                                        " per GPU (use sgnn_spmm_csr_f32 with a workspace)");
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(SGNN_ERR_INVALID, "device ordinal out of range");
+  void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (ptr == nullptr) {   // first call on this device: look its copy of the array up, once
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (ptr == nullptr) return fail(SGNN_ERR_HIP, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+  }
+  // spmm_impl clears the counters at the head of the scratch on the stream before it
+  // launches; everything else in it is written before it is read
+  return spmm_impl(n_rows, n_cols, F, rowptr, colidx, vals, dinv_row, dinv_col, X, ldx, Y, ldy, epilogue, nnz, ptr,
+                   kScratchBytes, static_cast<hipStream_t>(stream));
 }
 
 int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F, const int32_t* rowptr, const int32_t* colidx,
