@@ -285,6 +285,9 @@ def main():
     lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
     R = lib.sgnn_rowgroup_config(extra.get("features_per_rank", F))
     kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
+    tilegroup = world == 1 and bool(getattr(adj, "_tilegroup_plan", lambda F: None)(F))
+    if tilegroup:
+        kernel_path = "tile-group SpMM (512-row groups, fp16 hi/lo planes on v_mfma_f32_32x32x16_f16, fp32 accumulation)"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -358,7 +361,8 @@ def main():
                 "traffic": load_traffic(args.workload) if world == 1 else None,
                 "algorithmic_bytes": b_alg,
                 "kernel_ms": ev_ms,                           # HIP events around the K steps / K
-                "kernels_in_step": ("k_row_scale + k_rg_spmm + k_rg_combine"
+                "kernels_in_step": "k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine" if tilegroup else
+                                   ("k_row_scale + k_rg_spmm + k_rg_combine"
                                     + (" (rocprof, profiles/r01_reddit_f602_rowgroup_x4.json: 0.19 + 9.65 + 0.58 ms)"
                                        if args.workload == "reddit" and world == 1 else "")) if R
                                    else "k_spmm (+ k_row_scale)",

@@ -177,6 +177,56 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Tile-group SpMM: the adj.mm of utils.py:94 with its row scalings (utils.py:93, 95) for
+ * pattern-only adjacencies (all stored off-diagonal values equal) whose rows share many
+ * columns — the Reddit shape.  Groups of 512 degree-ranked rows share every fetched row of
+ * X through LDS; the sums run on the matrix cores (v_mfma_f32_32x32x16_f16, fp32
+ * accumulation) over X split into two fp16 planes that together reproduce every fp32 input
+ * to 2^-22 relative or better.  Results agree with sgnn_spmm_csr_f32 to fp32 rounding
+ * (different summation order), are reproducible run to run, and inputs the planes cannot
+ * represent (non-finite values, dynamic range beyond 2^28) are detected on the device and
+ * computed by the plain CSR kernel instead, with no host synchronisation.
+ *
+ * Plan (once per matrix), two steps because its size depends on the matrix:
+ *   sgnn_tilegroup_analyze  sorts and counts into `workspace`
+ *                           (sgnn_tilegroup_build_workspace_bytes); when the stream has
+ *                           drained, the first six int64 of `workspace` hold {merged
+ *                           (group, column) pairs, stages, steps, work items, partial
+ *                           slots, split groups}
+ *   sgnn_tilegroup_fill     writes the plan (sgnn_tilegroup_plan_bytes of those counts)
+ *                           from the same, untouched workspace
+ * Per operand:
+ *   sgnn_tilegroup_split_f32  planes <- fp16 hi / lo of (scale_row[i] * X[i, :]) (scale_row
+ *                           nullable; utils.py:93 when it is dinv); `state` is 16 bytes of
+ *                           device memory that carries the scale and the fall-back flag to
+ *                           the SpMM call that follows on the same stream
+ *   sgnn_spmm_tilegroup_f32   Y = diag(dinv_row) . (w_off * pattern) . planes, epilogue as
+ *                           sgnn_spmm_csr_f32.  rowptr / colidx / vals / dinv_col / X / ldx /
+ *                           csr_workspace describe the same product for the fall-back
+ *                           (X and dinv_col as given to the split call, csr_workspace of
+ *                           sgnn_spmm_workspace_bytes); rowptr == NULL: no fall-back is
+ *                           launched and Y is left untouched when state's flag is set.
+ */
+size_t sgnn_tilegroup_build_workspace_bytes(int64_t n_rows, int64_t nnz);
+size_t sgnn_tilegroup_plan_bytes(int64_t n_rows, int64_t stages, int64_t steps, int64_t items, int64_t long_groups);
+int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t stages, int64_t steps, int64_t items,
+                        int64_t long_groups, void* plan, size_t plan_bytes, void* workspace, size_t workspace_bytes,
+                        void* stream);
+size_t sgnn_tilegroup_planes_bytes(int64_t n_cols, int64_t F);
+int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, const float* X, int64_t ldx,
+                             void* planes, size_t planes_bytes, void* state, void* stream);
+size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F);
+int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
+                            int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
+                            const float* dinv_row, float w_off, const void* planes, size_t planes_bytes,
+                            const void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                            size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                            const float* vals, const float* dinv_col, const float* X, int64_t ldx,
+                            void* csr_workspace, size_t csr_workspace_bytes, void* stream);
+
+/*
  * Row-group form of a CSR's sparsity pattern, and the SpMM kernel that uses it.
  *
  * Rows are ranked by degree and cut into groups of R (8 or 16); a group stores

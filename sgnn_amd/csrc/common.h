@@ -30,6 +30,15 @@ int fail(int code, const std::string& msg);
 void set_rowgroup_segment(int cols);
 void set_rowgroup_order(int cols);   // column-block width the work items are ordered by (0 = default)
 void set_rowgroup_R(int R);   // 8 or 16: group size for plans built afterwards (0 = policy)
+void set_tilegroup_mode(int mode);        // diagnostic switches of the tile-group kernel (0 = normal)
+void set_tilegroup_segment(int stages);   // stages per tile-group work item for plans built afterwards
+
+// sgnn_spmm_csr_f32 whose kernels do nothing while the device word *guard is 0 (guard may
+// be NULL: always run).  Used as the fall-back behind the tile-group kernel.
+int spmm_csr_guarded(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, const int32_t* rowptr,
+                     const int32_t* colidx, const float* vals, const float* dinv_row, const float* dinv_col,
+                     const float* X, int64_t ldx, float* Y, int64_t ldy, int epilogue, void* workspace,
+                     size_t workspace_bytes, const uint32_t* guard, hipStream_t stream);
 
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \

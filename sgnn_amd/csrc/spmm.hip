@@ -42,6 +42,7 @@ struct SpmmArgs {
   int32_t* long_slot;  // [max_long] first partial slot of the row
   float* partial;      // [max_segs, F]
   int32_t max_segs, max_long;
+  const uint32_t* guard;   // nullable device word: the launch does nothing while it is 0
 };
 
 // ---- full-wavefront layout (LPR == 64) --------------------------------------
@@ -245,6 +246,7 @@ __device__ __forceinline__ void write_row(const SpmmArgs& a, float* dst, int32_t
 
 // list the rows longer than kSeg and give each of their segments a partial slot
 __global__ void k_collect_long(SpmmArgs a) {
+  if (a.guard != nullptr && *a.guard == 0) return;
   int64_t row = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (row >= a.n_rows) return;
   int32_t len = a.rowptr[row + 1] - a.rowptr[row];
@@ -267,6 +269,7 @@ __global__ void k_collect_long(SpmmArgs a) {
 // rows and write unscaled partial sums (combined by k_spmm_combine).
 template <int V, int LPR, int C, int U>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_spmm(SpmmArgs a, unsigned row_blocks) {
+  if (a.guard != nullptr && *a.guard == 0) return;
   const int wave = threadIdx.x / kWave;
   const int f0 = blockIdx.y * (LPR * V * C);
   float acc[C][V];
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_spmm(SpmmArgs a, unsi
 
 // sum a long row's partials in segment order, then the row epilogue
 __global__ void k_spmm_combine(SpmmArgs a) {
+  if (a.guard != nullptr && *a.guard == 0) return;
   const int32_t nlong = min(a.counters[1], a.max_long);
   const int32_t li = blockIdx.x;
   if (li >= nlong) return;
@@ -425,7 +429,8 @@ int dispatch_spmm(const SpmmArgs& a, hipStream_t st) {
 
 int spmm_impl(int64_t n_rows, int64_t n_cols, int64_t F, const int32_t* rowptr, const int32_t* colidx,
               const float* vals, const float* dinv_row, const float* dinv_col, const float* X, int64_t ldx, float* Y,
-              int64_t ldy, int epilogue, int64_t nnz_bound, void* workspace, size_t workspace_bytes, hipStream_t st) {
+              int64_t ldy, int epilogue, int64_t nnz_bound, void* workspace, size_t workspace_bytes, hipStream_t st,
+              const uint32_t* guard = nullptr) {
   if (n_rows < 0 || n_cols < 0 || F < 0) return fail(SGNN_ERR_INVALID, "negative size");
   if (n_rows == 0 || F == 0) return SGNN_OK;
   if (!rowptr || !colidx || !X || !Y) return fail(SGNN_ERR_INVALID, "null pointer");
@@ -449,6 +454,7 @@ int spmm_impl(int64_t n_rows, int64_t n_cols, int64_t F, const int32_t* rowptr, 
     return fail(SGNN_ERR_WORKSPACE, "spmm workspace too small: need " + std::to_string(w.total) + " bytes");
   a.counters = w.counters; a.seg_row = w.seg_row; a.seg_k = w.seg_k; a.long_row = w.long_row;
   a.long_slot = w.long_slot; a.partial = w.partial; a.max_segs = w.max_segs; a.max_long = w.max_long;
+  a.guard = guard;
   HIP_TRY(hipMemsetAsync(a.counters, 0, 256, st));
   hipLaunchKernelGGL(k_collect_long, dim3(unsigned((n_rows + 255) / 256)), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -469,6 +475,13 @@ std::atomic<void*> g_scratch_ptr[kMaxDevices];
 }  // namespace
 
 namespace sgnn {
+int spmm_csr_guarded(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, const int32_t* rowptr,
+                     const int32_t* colidx, const float* vals, const float* dinv_row, const float* dinv_col,
+                     const float* X, int64_t ldx, float* Y, int64_t ldy, int epilogue, void* workspace,
+                     size_t workspace_bytes, const uint32_t* guard, hipStream_t st) {
+  return spmm_impl(n_rows, n_cols, F, rowptr, colidx, vals, dinv_row, dinv_col, X, ldx, Y, ldy, epilogue, nnz, workspace,
+                   workspace_bytes, st, guard);
+}
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -487,6 +500,8 @@ int sgnn_tune_set(const char* key, int value) {
   else if (!std::strcmp(key, "rg_seg")) sgnn::set_rowgroup_segment(value);
   else if (!std::strcmp(key, "rg_R")) sgnn::set_rowgroup_R(value);
   else if (!std::strcmp(key, "rg_order")) sgnn::set_rowgroup_order(value);
+  else if (!std::strcmp(key, "tg_seg")) sgnn::set_tilegroup_segment(value);
+  else if (!std::strcmp(key, "tg_mode")) sgnn::set_tilegroup_mode(value);
   else return fail(SGNN_ERR_INVALID, std::string("unknown tuning key ") + key);
   return SGNN_OK;
 }

@@ -1,0 +1,1015 @@
+// Tile-group SpMM: 512 output rows share every fetched row of X, and the sums run on
+// the matrix cores.
+//
+// Where it comes from.  On graphs of Reddit's shape the row-group kernel (rowgroup.hip)
+// is bound by the rows of X it pulls from L2: with 16 output rows per wavefront the
+// benchmark graph needs 56 M row fetches of 2.4 KB (135 GB per hop).  The number of
+// distinct (group, column) pairs falls steadily with the group size (merged(R) on that
+// graph: R = 16 56.0 M, 128 24.3 M, 512 12.1 M), but a wavefront cannot hold more than
+// 16 rows of accumulators, and sharing fetched rows between the wavefronts of a
+// workgroup through LDS was tried with vector adds and lost to the mask arithmetic and
+// to barriers that wait for the busiest wavefront.
+//
+// What this kernel does instead.  A workgroup owns a group of 512 degree-ranked rows
+// (16 sub-tiles of 32 rows) and one 128-column slice of the features.  It walks the
+// group's merged column list in stages of 128 columns; a stage's rows of X arrive in LDS
+// by LDS-DMA (global_load_lds_dwordx4) while the stage before it is being multiplied.  Every sub-tile has, per stage,
+// its own packed list of the columns it actually uses, cut into steps of 16; a step is
+// one 32x16 0/1 pattern tile times a 16x32 tile of X per 32 features:
+// v_mfma_f32_32x32x16_f16, fp32 accumulation.  All wavefronts do the same kind of work
+// (no masks, no divergence), so a barrier per stage costs little, and the arithmetic a
+// pattern of zeros wastes is cheap at the matrix cores' rate.
+//
+// fp32 in, fp32 out, fp32 accumulation.  The matrix cores take 16-bit inputs, so X is
+// split beforehand (k_tg_split) into two fp16 planes, x * scale = hi + lo / 2048 with
+// scale a power of two that brings the largest magnitude just below 2^15; the pattern
+// tile is 1.0 for the hi plane and 2^-11 for the lo plane, so both land in the same
+// accumulator.  hi + lo / 2048 reproduces an fp32 input to 2^-24 relative, or to 2^-50 of
+// the largest magnitude in X where that is larger (elements more than 2^26 below the
+// largest); products with 0 / 1 / 2^-11 are exact and the sums are fp32, so the result
+// differs from the vector kernels' by summation order and at most one extra rounding of
+// each input.  The split pass checks every element, counts the ones that keep fewer than
+// 17 of their bits (more than 2^33 below the largest) and raises a flag when X is not
+// finite or holds more than one such element per million; the SpMM kernel then does
+// nothing and the fall-back launched behind it (the plain CSR kernel on the original
+// fp32 operand, guarded by the same flag) computes Y.
+//
+// Reference path served: the adj.mm of utils.py:94 with its two row scalings
+// (utils.py:93, 95) for adjacencies whose off-diagonal entries all carry one weight.
+#include <cstring>
+#include <type_traits>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+// the DMA helpers below set M0 inside their inline assembly and say so in the clobber list
+#pragma clang diagnostic ignored "-Winline-asm"
+
+namespace {
+using namespace sgnn;
+
+constexpr int kSub = 32;                         // rows of a sub-tile: M of one MFMA
+constexpr int kSubs = 16;                        // sub-tiles of a group
+constexpr int kRows = kSub * kSubs;              // 512 rows of a group
+constexpr int kStageCols = 128;                  // merged columns per stage
+constexpr int kSlotBits = 7;                     // log2(kStageCols)
+constexpr int kStepCols = 16;                    // K of one MFMA
+constexpr int kSlice = 128;                      // features of a slice (4 MFMA N-tiles)
+constexpr int kWaves = 8;
+constexpr int kRing = 2;                         // stages resident in LDS: one being read, one arriving
+constexpr int kRowBytes = 512;                   // one node's slice: hi 256 B | lo 256 B
+constexpr int kStageRowsBytes = kStageCols * kRowBytes;
+constexpr int kMaxStageSteps = kSubs * (kStageCols / kStepCols);   // 128
+constexpr int kSlotsBytes = kMaxStageSteps * 32;
+constexpr int kBitsBytes = kMaxStageSteps * 64;
+constexpr int kHdrBytes = 512;
+constexpr int kStageBytes = kStageRowsBytes + kSlotsBytes + kBitsBytes + kHdrBytes;   // 78336 = 153 * 512
+constexpr int kTableBytes = 128;
+constexpr int kLdsBytes = kRing * kStageBytes + kTableBytes;
+constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slack behind the step arrays (a stage's DMA over-reads)
+static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wavefront loads 16 rows of a stage");
+static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
+
+int g_seg_stages = 128;   // stages per work item; longer merged lists are cut (sgnn_tune_set("tg_seg", v))
+int g_order_cols = 4096;
+int g_tg_mode = 0;         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA; results are then wrong
+
+struct TgState {          // device words shared by the split pass and the SpMM
+  uint32_t amax_bits;     // bit pattern of max |scale_row * x|
+  uint32_t flag;          // != 0: X cannot go through the fp16 planes
+  float scale, inv_scale;
+  uint32_t tiny;          // nonzero elements more than 2^33 below the largest magnitude
+  uint32_t pad[3];
+};
+
+// ---- plan ------------------------------------------------------------------------
+struct TgPlan {
+  int64_t* counts;        // [8] merged, stages, steps, items, partial slots, long groups, stages per item
+  int32_t* grows;         // [G * 512] row of (group, slot), -1 = none
+  int32_t* gstage0;       // [G + 1] first stage of every group
+  int32_t* stage_col;     // [stages * 64] columns of a stage (tail of a group's last stage: its first column again)
+  int32_t* step0;         // [stages * 16 + 1 (+ slack)] first step of (stage, sub-tile)
+  uint16_t* step_slots;   // [(steps + slack) * 16] per column of a step: byte offset of its row in the stage's LDS image
+                          // (slot * 512, plus (slot & 3) * 64: the swizzle of the row's 64-byte segments)
+  uint16_t* step_bits;    // [(steps + slack) * 32] per row of the sub-tile: which of the 16 columns it has
+  int32_t *item_group, *item_s0, *item_s1, *item_out;   // [items] in launch order
+  int32_t *long_group, *long_slot, *long_nseg;          // [long groups]
+  int64_t G;
+  size_t total;
+};
+
+TgPlan carve_tg_plan(void* base, int64_t n_rows, int64_t stages, int64_t steps, int64_t items, int64_t n_long) {
+  TgPlan p{};
+  Carver c(base);
+  p.G = (n_rows + kRows - 1) / kRows;
+  p.counts = c.take<int64_t>(8);
+  p.grows = c.take<int32_t>(size_t(p.G) * kRows);
+  p.gstage0 = c.take<int32_t>(size_t(p.G) + 1);
+  p.stage_col = c.take<int32_t>(size_t(stages) * kStageCols + kStageCols);
+  p.step0 = c.take<int32_t>(size_t(stages) * kSubs + 1 + 128);   // the header DMA of the last stage reads 64 entries
+  p.step_slots = c.take<uint16_t>(size_t(steps + kPadSteps) * 16);
+  p.step_bits = c.take<uint16_t>(size_t(steps + kPadSteps) * 32);
+  p.item_group = c.take<int32_t>(size_t(items) + 1);
+  p.item_s0 = c.take<int32_t>(size_t(items) + 1);
+  p.item_s1 = c.take<int32_t>(size_t(items) + 1);
+  p.item_out = c.take<int32_t>(size_t(items) + 1);
+  p.long_group = c.take<int32_t>(size_t(n_long) + 1);
+  p.long_slot = c.take<int32_t>(size_t(n_long) + 1);
+  p.long_nseg = c.take<int32_t>(size_t(n_long) + 1);
+  p.total = c.off;
+  return p;
+}
+
+struct TgBuild {
+  int64_t* counts;
+  uint32_t *dkey_a, *dkey_b, *drow_a, *drow_b;
+  int32_t* rank;
+  uint64_t *keys_a, *keys_b;
+  uint32_t *head, *pos;
+  int32_t* mcol;            // [nnz] merged columns, all groups back to back
+  int32_t* gptr;            // [G + 1] merged-list offsets
+  uint32_t *gns, *gstage0;  // [G], [G + 1] stages per group and their running sum
+  uint32_t *runcount, *runfirst, *nsteps, *step0;   // [cap_runs (+1)]
+  uint32_t *nseg, *first, *lseg, *slot0, *lflag, *lidx;   // [G]
+  uint64_t *ikey_a, *ikey_b;   // [cap_items]
+  int32_t* itmp;               // [4 * cap_items]
+  void* prim;
+  size_t prim_bytes;
+  int64_t G, cap_stages, cap_runs, cap_items;
+  size_t total;
+};
+
+TgBuild carve_tg_build(void* base, int64_t n_rows, int64_t nnz) {
+  TgBuild w{};
+  Carver c(base);
+  w.G = (n_rows + kRows - 1) / kRows;
+  w.cap_stages = nnz / kStageCols + w.G + 1;
+  w.cap_runs = w.cap_stages * kSubs;
+  w.cap_items = w.G + w.cap_stages / 8 + 1;   // a group is cut only into pieces of at least 8 stages
+  w.counts = c.take<int64_t>(8);
+  w.dkey_a = c.take<uint32_t>(n_rows);
+  w.dkey_b = c.take<uint32_t>(n_rows);
+  w.drow_a = c.take<uint32_t>(n_rows);
+  w.drow_b = c.take<uint32_t>(n_rows);
+  w.rank = c.take<int32_t>(n_rows);
+  w.keys_a = c.take<uint64_t>(nnz);
+  w.keys_b = c.take<uint64_t>(nnz);
+  w.head = c.take<uint32_t>(nnz);
+  w.pos = c.take<uint32_t>(nnz);
+  w.mcol = c.take<int32_t>(nnz);
+  w.gptr = c.take<int32_t>(w.G + 1);
+  w.gns = c.take<uint32_t>(w.G + 1);
+  w.gstage0 = c.take<uint32_t>(w.G + 1);
+  w.runcount = c.take<uint32_t>(w.cap_runs + 1);
+  w.runfirst = c.take<uint32_t>(w.cap_runs + 1);
+  w.nsteps = c.take<uint32_t>(w.cap_runs + 1);
+  w.step0 = c.take<uint32_t>(w.cap_runs + 1);
+  w.nseg = c.take<uint32_t>(w.G);
+  w.first = c.take<uint32_t>(w.G);
+  w.lseg = c.take<uint32_t>(w.G);
+  w.slot0 = c.take<uint32_t>(w.G);
+  w.lflag = c.take<uint32_t>(w.G);
+  w.lidx = c.take<uint32_t>(w.G);
+  w.ikey_a = c.take<uint64_t>(w.cap_items);
+  w.ikey_b = c.take<uint64_t>(w.cap_items);
+  w.itmp = c.take<int32_t>(4 * w.cap_items);
+  size_t s1 = 0, s2 = 0, s3 = 0;
+  uint64_t* k64 = nullptr;
+  uint32_t* k32 = nullptr;
+  (void)rocprim::radix_sort_keys(nullptr, s1, k64, k64, size_t(nnz > w.cap_items ? nnz : w.cap_items), 0u, 64u,
+                                 hipStream_t(0));
+  (void)rocprim::radix_sort_pairs(nullptr, s2, k32, k32, k32, k32, size_t(n_rows), 0u, 32u, hipStream_t(0));
+  const size_t scan_n = size_t(nnz > w.cap_runs + 1 ? nnz : w.cap_runs + 1);
+  (void)rocprim::exclusive_scan(nullptr, s3, k32, k32, 0u, scan_n, rocprim::plus<uint32_t>(), hipStream_t(0));
+  w.prim_bytes = align_up(s1 > s2 ? (s1 > s3 ? s1 : s3) : (s2 > s3 ? s2 : s3));
+  w.prim = c.take<char>(w.prim_bytes);
+  w.total = c.off;
+  return w;
+}
+
+// ---- plan construction, phase 0: sizes --------------------------------------------
+__global__ void k_tg_deg_keys(int64_t n, const int32_t* __restrict__ rowptr, uint32_t* __restrict__ key,
+                              uint32_t* __restrict__ row) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  key[i] = 0xFFFFFFFFu - uint32_t(rowptr[i + 1] - rowptr[i]);   // ascending key = descending degree
+  row[i] = uint32_t(i);
+}
+
+__global__ void k_tg_rank(int64_t n, const uint32_t* __restrict__ order, int32_t* __restrict__ rank) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i < n) rank[order[i]] = int32_t(i);
+}
+
+// key of an entry = (group of its row, column, slot of its row in the group: 9 bits)
+__global__ void k_tg_entry_keys(int64_t n, int64_t nnz, const int32_t* __restrict__ rowptr,
+                                const int32_t* __restrict__ colidx, const int32_t* __restrict__ rank, int cbits,
+                                uint64_t* __restrict__ keys) {
+  int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (e >= nnz) return;
+  int64_t lo = 0, hi = n;   // last row whose rowptr <= e
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (int64_t(rowptr[mid]) <= e) lo = mid; else hi = mid;
+  }
+  const uint32_t rk = uint32_t(rank[lo]);
+  keys[e] = (((uint64_t(rk / kRows) << cbits) | uint64_t(colidx[e])) << 9) | uint64_t(rk % kRows);
+}
+
+__global__ void k_tg_heads(int64_t nnz, const uint64_t* __restrict__ keys, int shift, uint32_t* __restrict__ head) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= nnz) return;
+  head[i] = (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1u : 0u;
+}
+
+// merged columns back to back; group offsets (groups without entries get empty lists)
+__global__ void k_tg_merged(int64_t G, int64_t nnz, const uint64_t* __restrict__ keys,
+                            const uint32_t* __restrict__ head, const uint32_t* __restrict__ pos, int cbits,
+                            int32_t* __restrict__ mcol, int32_t* __restrict__ gptr, int64_t* __restrict__ counts) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= nnz) return;
+  const int64_t merged = int64_t(pos[nnz - 1]) + head[nnz - 1];
+  if (head[i]) {
+    const uint64_t gc = keys[i] >> 9;
+    mcol[pos[i]] = int32_t(gc & ((uint64_t(1) << cbits) - 1));
+    const int64_t g = int64_t(gc >> cbits);
+    const int64_t gprev = i == 0 ? -1 : int64_t(keys[i - 1] >> (9 + cbits));
+    for (int64_t q = gprev + 1; q <= g; ++q) gptr[q] = int32_t(pos[i]);
+  }
+  if (i == nnz - 1) {
+    const int64_t glast = int64_t(keys[i] >> (9 + cbits));
+    for (int64_t q = glast + 1; q <= G; ++q) gptr[q] = int32_t(merged);
+    counts[0] = merged;
+  }
+}
+
+__global__ void k_tg_group_stages(int64_t G, const int32_t* __restrict__ gptr, uint32_t* __restrict__ gns) {
+  int64_t g = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (g > G) return;
+  gns[g] = g < G ? uint32_t((gptr[g + 1] - gptr[g] + kStageCols - 1) / kStageCols) : 0u;
+}
+
+// second key of an entry = (stage, sub-tile of its row, slot of its column in the stage, row in the sub-tile)
+__global__ void k_tg_step_keys(int64_t nnz, const uint64_t* __restrict__ keys1, const uint32_t* __restrict__ head,
+                               const uint32_t* __restrict__ pos, const int32_t* __restrict__ gptr, const uint32_t* __restrict__ gstage0, int cbits,
+                               uint64_t* __restrict__ keys2) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= nnz) return;
+  const uint64_t k = keys1[i];
+  const int64_t g = int64_t(k >> (9 + cbits));
+  const uint32_t r9 = uint32_t(k & 511);
+  // pos[] is the exclusive scan of the heads: an entry that is not a head sits in merged column pos[i] - 1
+  const uint32_t m = (head[i] ? pos[i] : pos[i] - 1u) - uint32_t(gptr[g]);
+  const uint64_t stage = uint64_t(gstage0[g]) + m / kStageCols;
+  keys2[i] = ((stage * kSubs + (r9 >> 5)) << (5 + kSlotBits)) | (uint64_t(m % kStageCols) << 5) | uint64_t(r9 & 31);
+}
+
+// columns of every (stage, sub-tile) run, and where the run's first (sub-tile, column) pair sits
+__global__ void k_tg_run_counts(int64_t nnz, const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ head,
+                                const uint32_t* __restrict__ pair, uint32_t* __restrict__ runcount,
+                                uint32_t* __restrict__ runfirst) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= nnz || !head[i]) return;
+  const uint64_t run = keys2[i] >> (5 + kSlotBits);
+  atomicAdd(&runcount[run], 1u);
+  if (i == 0 || (keys2[i - 1] >> (5 + kSlotBits)) != run) runfirst[run] = pair[i];
+}
+
+__global__ void k_tg_run_steps(int64_t runs_cap, const int64_t* __restrict__ counts, const uint32_t* __restrict__ gstage0,
+                               int64_t G, const uint32_t* __restrict__ runcount, uint32_t* __restrict__ nsteps) {
+  int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (r > runs_cap) return;
+  const int64_t runs = int64_t(gstage0[G]) * kSubs;
+  nsteps[r] = r < runs ? (runcount[r] + kStepCols - 1) / kStepCols : 0u;
+  (void)counts;
+}
+
+// work items: a group's stages in pieces of about `seg` stages
+__global__ void k_tg_nseg(int64_t G, int seg, const uint32_t* __restrict__ gns, uint32_t* __restrict__ nseg,
+                          uint32_t* __restrict__ lseg, uint32_t* __restrict__ lflag) {
+  int64_t g = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t ns = gns[g];
+  const uint32_t pieces = ns > uint32_t(seg + seg / 4) ? (ns + seg - 1) / seg : 1u;   // an empty group still writes its zero rows
+  nseg[g] = pieces;
+  lseg[g] = pieces > 1 ? pieces : 0u;
+  lflag[g] = pieces > 1 ? 1u : 0u;
+}
+
+__global__ void k_tg_totals(int64_t G, const uint32_t* __restrict__ gstage0, const uint32_t* __restrict__ step0,
+                            const uint32_t* __restrict__ nseg, const uint32_t* __restrict__ first,
+                            const uint32_t* __restrict__ lseg, const uint32_t* __restrict__ slot0,
+                            const uint32_t* __restrict__ lflag, const uint32_t* __restrict__ lidx, int seg,
+                            int64_t* __restrict__ counts) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int64_t stages = gstage0[G];
+  counts[1] = stages;
+  counts[2] = step0[stages * kSubs];
+  counts[3] = G > 0 ? int64_t(first[G - 1]) + nseg[G - 1] : 0;
+  counts[4] = G > 0 ? int64_t(slot0[G - 1]) + lseg[G - 1] : 0;
+  counts[5] = G > 0 ? int64_t(lidx[G - 1]) + lflag[G - 1] : 0;
+  counts[6] = seg;
+}
+
+// ---- plan construction, phase 1: contents -----------------------------------------
+__global__ void k_tg_grows(int64_t n, int64_t slots, const uint32_t* __restrict__ order, int32_t* __restrict__ grows) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i < slots) grows[i] = i < n ? int32_t(order[i]) : -1;
+}
+
+__global__ void k_tg_copy_u32(int64_t count, const uint32_t* __restrict__ src, int32_t* __restrict__ dst,
+                              int64_t fill_to) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i < count) dst[i] = int32_t(src[i]);
+  else if (i < fill_to) dst[i] = int32_t(src[count - 1]);   // slack behind the last entry repeats it
+}
+
+__global__ void k_tg_stage_cols(int64_t G, int64_t stages, const int32_t* __restrict__ gptr,
+                                const uint32_t* __restrict__ gstage0, const int32_t* __restrict__ mcol,
+                                int32_t* __restrict__ stage_col) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= stages * kStageCols) return;
+  const int64_t stage = i / kStageCols;
+  const int slot = int(i % kStageCols);
+  int64_t lo = 0, hi = G;   // last group whose first stage <= stage
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (int64_t(gstage0[mid]) <= stage) lo = mid; else hi = mid;
+  }
+  // groups without stages share their first stage with the next group: skip to the one that owns it
+  while (lo + 1 < G && gstage0[lo + 1] == gstage0[lo] && int64_t(gstage0[lo]) == stage) ++lo;
+  const int64_t m0 = (stage - gstage0[lo]) * kStageCols;
+  const int64_t len = gptr[lo + 1] - gptr[lo];
+  const int64_t m = m0 + slot < len ? m0 + slot : m0;
+  stage_col[i] = mcol[gptr[lo] + m];
+}
+
+__global__ void k_tg_fill_steps(int64_t nnz, const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ head,
+                                const uint32_t* __restrict__ pair, const uint32_t* __restrict__ runfirst,
+                                const uint32_t* __restrict__ step0, uint16_t* __restrict__ step_slots,
+                                uint32_t* __restrict__ step_bits32) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= nnz) return;
+  const uint64_t k = keys2[i];
+  const uint64_t run = k >> (5 + kSlotBits);
+  const uint32_t slot = uint32_t(k >> 5) & uint32_t(kStageCols - 1), r5 = uint32_t(k) & 31u;
+  // pair[] is the exclusive scan of the heads: an entry that is not a head belongs to pair[i] - 1
+  const uint32_t pi = head[i] ? pair[i] : pair[i] - 1u;
+  const uint32_t j = pi - runfirst[run];
+  const int64_t step = int64_t(step0[run]) + j / kStepCols;
+  const uint32_t kpos = j % kStepCols;
+  if (head[i]) step_slots[step * 16 + kpos] = uint16_t(slot * kRowBytes + ((slot & 3u) << 6));
+  atomicOr(&step_bits32[step * 16 + (r5 >> 1)], 1u << (kpos + 16u * (r5 & 1u)));
+}
+
+__global__ void k_tg_items(int64_t G, const uint32_t* __restrict__ gns, const uint32_t* __restrict__ gstage0,
+                           const uint32_t* __restrict__ nseg, const uint32_t* __restrict__ first,
+                           const uint32_t* __restrict__ slot0, const uint32_t* __restrict__ lidx,
+                           int32_t* __restrict__ tmp, int64_t cap, int32_t* __restrict__ long_group,
+                           int32_t* __restrict__ long_slot, int32_t* __restrict__ long_nseg) {
+  int64_t g = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t pieces = nseg[g], ns = gns[g];
+  for (uint32_t k = 0; k < pieces; ++k) {
+    const uint32_t it = first[g] + k;
+    tmp[it] = int32_t(g);
+    tmp[cap + it] = int32_t(gstage0[g] + uint64_t(ns) * k / pieces);
+    tmp[2 * cap + it] = int32_t(gstage0[g] + uint64_t(ns) * (k + 1) / pieces);
+    tmp[3 * cap + it] = pieces > 1 ? int32_t(slot0[g] + k) : -1;
+  }
+  if (pieces > 1) {
+    long_group[lidx[g]] = int32_t(g);
+    long_slot[lidx[g]] = int32_t(slot0[g]);
+    long_nseg[lidx[g]] = int32_t(pieces);
+  }
+}
+
+// Launch order: by the column block an item's first stage starts in, so that workgroups
+// running at the same time walk the same stretch of X and meet each other's rows in L2.
+__global__ void k_tg_item_keys(int64_t items, const int32_t* __restrict__ tmp, int64_t cap,
+                               const int32_t* __restrict__ stage_col, int order_cols, uint64_t* __restrict__ keys) {
+  int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (it >= items) return;
+  const int64_t s0 = tmp[cap + it];
+  keys[it] = (uint64_t(stage_col[s0 * kStageCols] / order_cols) << 32) | uint64_t(it);
+}
+
+__global__ void k_tg_item_place(int64_t items, const uint64_t* __restrict__ keys, const int32_t* __restrict__ tmp,
+                                int64_t cap, int32_t* __restrict__ a, int32_t* __restrict__ b,
+                                int32_t* __restrict__ c, int32_t* __restrict__ d) {
+  int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (it >= items) return;
+  const int64_t src = int64_t(keys[it] & 0xffffffffu);
+  a[it] = tmp[src];
+  b[it] = tmp[cap + src];
+  c[it] = tmp[2 * cap + src];
+  d[it] = tmp[3 * cap + src];
+}
+
+// ---- fp16 planes --------------------------------------------------------------------
+__global__ void k_tg_amax(int64_t n, int64_t F, const float* __restrict__ scale_row, const float* __restrict__ X,
+                          int64_t ldx, TgState* __restrict__ state) {
+  uint32_t m = 0;
+  const int64_t total = n * F;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / F;
+    const float v = X[r * ldx + (i - r * F)] * (scale_row ? scale_row[r] : 1.0f);
+    const uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu;   // |v|; NaN and inf compare above every finite value
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = uint32_t(__shfl_xor(int(m), off));
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && m != 0) atomicMax(&state->amax_bits, m);
+}
+
+// the power of two that brings amax into [2^14, 2^15)
+__device__ __forceinline__ float tg_scale(uint32_t amax_bits) {
+  if (amax_bits == 0 || amax_bits >= 0x7F800000u) return 1.0f;
+  int e = int(amax_bits >> 23) - 127;
+  if (e < -126) e = -126;
+  int s = 14 - e;
+  if (s > 126) s = 126;
+  return __builtin_bit_cast(float, uint32_t(s + 127) << 23);
+}
+
+// planes[slice][node] = 128 halfs hi | 128 halfs lo of (scale_row[node] * X[node, slice]) * scale;
+// one thread per (node, 8 features)
+__global__ __launch_bounds__(256) void k_tg_split(int64_t n, int64_t F, int64_t n_slices,
+                                                  const float* __restrict__ scale_row, const float* __restrict__ X,
+                                                  int64_t ldx, char* __restrict__ planes, TgState* __restrict__ state) {
+  const int64_t chunks = n_slices * (kSlice / 8);
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  const uint32_t amax = state->amax_bits;
+  const float scale = tg_scale(amax);
+  if (i == 0) {
+    state->scale = scale;
+    state->inv_scale = 1.0f / scale;
+    if (amax >= 0x7F800000u) atomicOr(&state->flag, 1u);
+  }
+  if (i >= n * chunks) return;
+  const int64_t node = i / chunks;
+  const int c = int(i - node * chunks);
+  const int slice = c / (kSlice / 8), within = c % (kSlice / 8);
+  const float sr = scale_row ? scale_row[node] : 1.0f;
+  const float* src = X + node * ldx + int64_t(c) * 8;
+  _Float16 hi[8], lo[8];
+  bool bad = false;
+  uint32_t tiny = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = (int64_t(c) * 8 + j < F) ? src[j] * sr : 0.0f;   // the reference's scaling (utils.py:93), fp32
+    const float xs = x * scale;
+    const _Float16 h = _Float16(xs);
+    const float r = xs - float(h);
+    const _Float16 l = _Float16(r * 2048.0f);
+    const float back = float(h) + float(l) * (1.0f / 2048.0f);
+    // hi + lo / 2048 carries 22 bits of the input down to the spacing of the lo plane's
+    // subnormals (2^-35 here, 2^-50 of the largest magnitude); `!(<=)` also catches NaN
+    const float ax = __builtin_fabsf(xs);
+    bad |= !(__builtin_fabsf(xs - back) <= __builtin_fmaxf(ax * 4.8e-7f, 3.0e-11f));
+    tiny += (x != 0.0f && ax < 1.9e-6f) ? 1u : 0u;   // below 2^-19 (or flushed to 0): fewer than 17 of its bits survive
+    hi[j] = h;
+    lo[j] = l;
+  }
+  if (tiny) atomicAdd(&state->tiny, tiny);
+  char* dst = planes + ((int64_t(slice) * n + node) * kRowBytes) + within * 16;
+  *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(hi);
+  *reinterpret_cast<uint4*>(dst + 256) = *reinterpret_cast<const uint4*>(lo);
+  if (bad) atomicOr(&state->flag, 1u);
+}
+
+// A continuous distribution leaves a handful of such elements among 10^8 (they change a sum
+// by less than 2^-50 of the largest magnitude each); data with a genuinely wide dynamic
+// range has them by the thousand and goes to the fall-back kernel.
+__global__ void k_tg_finish(TgState* __restrict__ state, uint32_t tiny_limit) {
+  if (state->tiny > tiny_limit) atomicOr(&state->flag, 2u);
+}
+
+// ---- the kernel -----------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct TgArgs {
+  const int32_t *grows, *stage_col, *step0;
+  const uint16_t* step_slots;
+  const uint16_t* step_bits;
+  const int32_t *item_group, *item_s0, *item_s1, *item_out;
+  const int32_t *long_group, *long_slot, *long_nseg;
+  const char* planes;
+  const TgState* state;
+  const float* dinv_row;
+  float *Y, *partial;
+  int64_t ldy, slice_bytes;   // slice_bytes = n_cols * 512
+  int32_t items, n_long, F, Fpad, epilogue;
+  float w_off;
+  int32_t mode;
+};
+
+// LDS-DMA: 64 lanes x 16 (4) bytes from per-lane global addresses to LDS [lds, lds + 1024 (256)).
+// Issued through inline assembly so that the compiler does not order later LDS reads behind
+// it (it would wait for every outstanding DMA before the first read of any stage); the
+// kernel waits for the stage it needs with counted s_waitcnt vmcnt itself.
+__device__ __forceinline__ void tg_dma16(const void* g, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+}
+// the same with the global address as a wave-uniform base plus a 32-bit per-lane byte offset
+__device__ __forceinline__ void tg_dma16_off(const void* base, uint32_t off, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void tg_dma4(const void* g, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+}
+
+// One workgroup per (work item, feature slice); 8 wavefronts, wavefront w owns sub-tiles w and 15 - w.
+template <int NT>
+__global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  if (a.state->flag != 0) return;   // X did not fit the fp16 planes: the fall-back kernel computes Y
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int item = blockIdx.x, slice = blockIdx.y;
+  const int g = a.item_group[item], s0 = a.item_s0[item], s1 = a.item_s1[item], out = a.item_out[item];
+  const uint32_t lds0 = uint32_t(uintptr_t((__attribute__((address_space(3))) char*)smem));
+  const char* xs = a.planes + int64_t(slice) * a.slice_bytes;
+
+  // pattern tile from a nibble of row bits: two dwords of fp16 pairs, 1.0 where the bit is set
+  uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + kRing * kStageBytes);
+  if (tid < 16) {
+    tbl[2 * tid] = ((tid & 1) ? 0x3C00u : 0u) | ((tid & 2) ? 0x3C000000u : 0u);
+    tbl[2 * tid + 1] = ((tid & 4) ? 0x3C00u : 0u) | ((tid & 8) ? 0x3C000000u : 0u);
+  }
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[tt][nt][v] = 0.0f;
+
+  // lane constants of the transposed reads: lane = 32 h + 16 g1 + 4 q + p supplies the address
+  // of columns 16 g1 + 4 p .. + 3 of the row whose k index is 8 h + 4 r + q (read r = 0, 1)
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const uint32_t lane_off = uint32_t(32 * g1 + 8 * p);
+  const uint32_t offs_off = uint32_t(kStageRowsBytes + 2 * (8 * h + q));   // this lane's entry of a step's offsets (r = 0)
+  const uint32_t bits_off = uint32_t(kStageRowsBytes + kSlotsBytes + 2 * (lane & 31) + h);
+  // source offset of this lane's 16 bytes inside a node's 512-byte slice for the two
+  // slot classes a wavefront's rows alternate between (slot & 3 = h and 2 + h)
+  const uint32_t pc = uint32_t(lane & 31);
+  const uint32_t swz_even = (((pc >> 2) ^ uint32_t(h)) << 6) | ((pc & 3u) << 4);
+  const uint32_t swz_odd = (((pc >> 2) ^ uint32_t(2 + h)) << 6) | ((pc & 3u) << 4);
+  const bool small = a.slice_bytes < (int64_t(1) << 32);   // row offsets fit 32 bits
+
+  // A stage's column ids and first step are wave-uniform and read through the constant
+  // address space, i.e. by scalar loads: a vector load here would enter the vmcnt queue
+  // in front of the DMAs.
+  typedef int i32x16 __attribute__((ext_vector_type(16)));
+  typedef const __attribute__((address_space(4))) i32x16* c16ptr;
+  typedef const __attribute__((address_space(4))) int32_t* c1ptr;
+  auto stage_cols = [&](int s) {
+    return *reinterpret_cast<c16ptr>(uintptr_t(a.stage_col + int64_t(s) * kStageCols + w * 16));
+  };
+  auto stage_first_step = [&](int s) {
+    return *reinterpret_cast<c1ptr>(uintptr_t(a.step0 + int64_t(s) * kSubs));
+  };
+  // Stage s into ring buffer (s - s0) % 2: wavefront w brings rows 16 w .. 16 w + 15 (two per
+  // instruction) and a share of the stage's step records.
+  auto issue = [&](int s, i32x16 cols, int sf32) {
+    const uint32_t buf = lds0 + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
+    if (!(a.mode & 2)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // (kept as two scalar values: written as one select of vector elements the compiler
+        // turns it into a lane-indexed element access, a chain of 16 compares per row)
+        const uint32_t c_even = uint32_t(__builtin_amdgcn_readfirstlane(cols[2 * i]));
+        const uint32_t c_odd = uint32_t(__builtin_amdgcn_readfirstlane(cols[2 * i + 1]));
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(8 * w + i) * 1024u);
+        if (small) {
+          const uint32_t off = (h ? c_odd * uint32_t(kRowBytes) : c_even * uint32_t(kRowBytes)) | ((i & 1) ? swz_odd : swz_even);
+          tg_dma16_off(xs, off, dst);
+        } else {
+          const int64_t col = h ? c_odd : c_even;
+          tg_dma16(xs + col * kRowBytes + ((i & 1) ? swz_odd : swz_even), dst);
+        }
+      }
+    }
+    const int64_t sf = sf32;
+    const uint32_t rec = buf + kStageRowsBytes;
+    if (w >= 6) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        tg_dma16(reinterpret_cast<const char*>(a.step_slots) + sf * 32 + ((w - 6) * 2 + i) * 1024 + lane * 16,
+                 __builtin_amdgcn_readfirstlane(rec + uint32_t((w - 6) * 2 + i) * 1024u));
+    } else if (w >= 1 && w <= 4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        tg_dma16(reinterpret_cast<const char*>(a.step_bits) + sf * 64 + ((w - 1) * 2 + i) * 1024 + lane * 16,
+                 __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + uint32_t((w - 1) * 2 + i) * 1024u));
+    } else if (w == 5) {
+      tg_dma4(a.step0 + int64_t(s) * kSubs + lane, __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + kBitsBytes));
+    }
+  };
+
+  const int ns = s1 - s0;
+  const int last = s1 - 1;
+  if (ns > 0) issue(s0, stage_cols(s0), stage_first_step(s0));
+  // ids of the stage issued in the next iteration, fetched one iteration early
+  i32x16 ncols = stage_cols(min(s0 + 1, last));
+  int nsf = stage_first_step(min(s0 + 1, last));
+
+  for (int k = 0; k < ns; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of stage k has landed
+    __builtin_amdgcn_s_barrier();                      // everyone's has; stage k - 1 is no longer read
+    asm volatile("" ::: "memory");
+    if (k + 1 < ns) issue(s0 + k + 1, ncols, nsf);
+    ncols = stage_cols(min(s0 + k + 2, last));
+    nsf = stage_first_step(min(s0 + k + 2, last));
+
+    const uint32_t boff = uint32_t(k & (kRing - 1)) * kStageBytes;
+    const int* hdr = reinterpret_cast<const int*>(smem + boff + kStageRowsBytes + kSlotsBytes + kBitsBytes);
+    const int sf = __builtin_amdgcn_readfirstlane(hdr[0]);
+    // this wavefront's steps of the stage: those of sub-tile w, then those of sub-tile 15 - w
+    // (rows are ranked by degree, so the two lists together are about equally long for every w)
+    const int b0 = __builtin_amdgcn_readfirstlane(hdr[w]) - sf;
+    const int n0 = __builtin_amdgcn_readfirstlane(hdr[w + 1]) - sf - b0;
+    const int b1 = __builtin_amdgcn_readfirstlane(hdr[kSubs - 1 - w]) - sf;
+    const int total = n0 + __builtin_amdgcn_readfirstlane(hdr[kSubs - w]) - sf - b1;
+
+    // A step's record as this lane needs it: the LDS offsets of the two rows it addresses
+    // in the transposed reads, and its 8 row bits.
+    auto record = [&](int j, uint32_t& off_a, uint32_t& off_b, uint32_t& bt) {
+      const uint32_t ls = uint32_t(j < n0 ? b0 + j : b1 + (j - n0));
+      const char* o = smem + boff + offs_off + ls * 32;
+      off_a = *reinterpret_cast<const uint16_t*>(o);
+      off_b = *reinterpret_cast<const uint16_t*>(o + 8);
+      bt = *reinterpret_cast<const uint8_t*>(smem + boff + bits_off + ls * 64);
+    };
+    auto pattern = [&](uint32_t bt) {
+      const uint2 t0 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tbl) + (bt & 15u) * 8u);
+      const uint2 t1 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tbl) + (bt >> 4) * 8u);
+      return u32x4{t0.x, t0.y, t1.x, t1.y};
+    };
+    auto read_tile = [&](uint32_t base_a, uint32_t base_b, int pl, int nt) {
+      const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) hv4*)(smem + ((base_a ^ uint32_t(nt << 6)) + pl * 256)));
+      const hv4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) hv4*)(smem + ((base_b ^ uint32_t(nt << 6)) + pl * 256)));
+      h8 r;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        r[jj] = _Float16(f0[jj]);
+        r[4 + jj] = _Float16(f1[jj]);
+      }
+      return r;
+    };
+    // Software pipeline over the steps.  Behind every MFMA of step j the reads of the same tile
+    // of X for step j + 1 go out into the registers that MFMA has just consumed, so a read has
+    // seven MFMAs of this wavefront (and the other wavefront's on the SIMD) to arrive; the
+    // record of step j + 2 and the pattern tile of step j + 1 are fetched at the top.  The
+    // last steps prefetch the final step again: no branches in the body.  One loop per
+    // sub-tile, so that the accumulators are addressed statically; the prefetch runs across
+    // the seam between the two lists.
+    if (total > 0 && !(a.mode & 1)) {
+      u32x4 ahi;                                  // pattern tile of the current step
+      uint32_t base_a, base_b;                    // row addresses of the step whose tiles are being read
+      uint32_t off_a, off_b, bt;                  // record of the step after that
+      h8 bh[NT], bl[NT];
+      record(0, off_a, off_b, bt);
+      ahi = pattern(bt);
+      base_a = boff + lane_off + off_a;
+      base_b = boff + lane_off + off_b;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, 0, nt);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, 1, nt);
+      record(min(1, total - 1), off_a, off_b, bt);
+      auto body = [&](auto tt_tag, int j) {
+        constexpr int TT = decltype(tt_tag)::value;
+        // step j + 1: its record is here; pattern tile and row addresses
+        const u32x4 anext = pattern(bt);
+        base_a = boff + lane_off + off_a;
+        base_b = boff + lane_off + off_b;
+        record(min(j + 2, total - 1), off_a, off_b, bt);
+        const h8 fhi = __builtin_bit_cast(h8, ahi);
+        const h8 flo = __builtin_bit_cast(h8, ahi & 0x10001000u);   // 1.0 -> 2^-11: the lo plane holds the remainder times 2048
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi, bh[nt], acc[TT][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bh[nt] = read_tile(base_a, base_b, 0, nt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo, bl[nt], acc[TT][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bl[nt] = read_tile(base_a, base_b, 1, nt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ahi = anext;
+      };
+      int j = 0;
+      for (; j < n0; ++j) body(std::integral_constant<int, 0>{}, j);
+      for (; j < total; ++j) body(std::integral_constant<int, 1>{}, j);
+    }
+  }
+
+  // accumulator register v of a lane: row (v & 3) + 8 (v >> 2) + 4 h of the sub-tile, feature lane & 31 of the N-tile
+  const float inv_scale = a.state->inv_scale;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = tt == 0 ? w : kSubs - 1 - w;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int rr = kSub * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+      const int row = a.grows[int64_t(g) * kRows + rr];
+      if (row < 0) continue;
+      float dr = 1.0f;
+      if (out < 0 && a.dinv_row != nullptr) dr = a.dinv_row[row];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int f = slice * kSlice + nt * 32 + (lane & 31);
+        float y = acc[tt][nt][v] * inv_scale;   // exact: a power of two
+        if (out < 0) {
+          if (f >= a.F) continue;
+          if (a.w_off != 1.0f) y *= a.w_off;
+          if (a.dinv_row != nullptr) {
+            y = y * dr;
+            if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+          }
+          a.Y[int64_t(row) * a.ldy + f] = y;
+        } else {
+          a.partial[(int64_t(out) * kRows + rr) * a.Fpad + f] = y;
+        }
+      }
+    }
+  }
+}
+
+// rows of a group cut into several items: add the items' partial rows in order, then the row epilogue
+__global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
+  if (a.state->flag != 0) return;
+  const int li = blockIdx.x;
+  const int g = a.long_group[li], slot = a.long_slot[li], nseg = a.long_nseg[li];
+  for (int rr = blockIdx.y; rr < kRows; rr += gridDim.y) {
+    const int row = a.grows[int64_t(g) * kRows + rr];
+    if (row < 0) continue;
+    const bool scale = a.dinv_row != nullptr;
+    const float dr = scale ? a.dinv_row[row] : 1.0f;
+    for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
+      const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f;
+      const int64_t stride = int64_t(kRows) * a.Fpad;
+      float s = 0.0f;
+      for (int k = 0; k < nseg; ++k) s += pp[k * stride];
+      if (a.w_off != 1.0f) s *= a.w_off;
+      if (scale) {
+        s = s * dr;
+        if (a.epilogue == SGNN_EPI_SCALE_ROW2) s = s * dr;
+      }
+      a.Y[int64_t(row) * a.ldy + f] = s;
+    }
+  }
+}
+
+dim3 blocks_for(int64_t items, unsigned T = 256) { return dim3(unsigned((items + T - 1) / T)); }
+
+}  // namespace
+
+namespace sgnn {
+void set_tilegroup_mode(int m) { g_tg_mode = m; }
+void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 128; }
+}  // namespace sgnn
+
+extern "C" {
+
+size_t sgnn_tilegroup_build_workspace_bytes(int64_t n_rows, int64_t nnz) {
+  if (n_rows <= 0 || nnz <= 0) return 0;
+  return carve_tg_build(nullptr, n_rows, nnz).total;
+}
+
+size_t sgnn_tilegroup_plan_bytes(int64_t n_rows, int64_t stages, int64_t steps, int64_t items, int64_t long_groups) {
+  if (n_rows <= 0 || stages < 0 || steps < 0 || items < 0 || long_groups < 0) return 0;
+  return carve_tg_plan(nullptr, n_rows, stages, steps, items, long_groups).total;
+}
+
+int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_rows <= 0 || n_cols <= 0 || nnz <= 0) return fail(SGNN_ERR_INVALID, "empty matrix");
+  if (n_rows >= (int64_t(1) << 31) || n_cols >= (int64_t(1) << 31) || nnz >= (int64_t(1) << 31))
+    return fail(SGNN_ERR_INVALID, "size exceeds int32 index range");
+  if (!rowptr || !colidx || !workspace) return fail(SGNN_ERR_INVALID, "null pointer");
+  TgBuild w = carve_tg_build(workspace, n_rows, nnz);
+  if (workspace_bytes < w.total) return fail(SGNN_ERR_WORKSPACE, "tile-group build workspace too small");
+  const int cbits = ceil_log2(n_cols);
+  const int gbits = ceil_log2(w.G + 1);
+  if (9 + cbits + gbits > 64) return fail(SGNN_ERR_INVALID, "key does not fit 64 bits");
+  const int rbits = ceil_log2(w.cap_runs + 1);
+  if (5 + kSlotBits + rbits > 64) return fail(SGNN_ERR_INVALID, "key does not fit 64 bits");
+  const unsigned T = 256;
+  HIP_TRY(hipMemsetAsync(w.counts, 0, 64, st));
+  // rank the rows by degree (stable: ties keep row order)
+  hipLaunchKernelGGL(k_tg_deg_keys, blocks_for(n_rows), dim3(T), 0, st, n_rows, rowptr, w.dkey_a, w.drow_a);
+  HIP_TRY(hipGetLastError());
+  size_t pb = w.prim_bytes;
+  HIP_TRY(rocprim::radix_sort_pairs(w.prim, pb, w.dkey_a, w.dkey_b, w.drow_a, w.drow_b, size_t(n_rows), 0u, 32u, st));
+  hipLaunchKernelGGL(k_tg_rank, blocks_for(n_rows), dim3(T), 0, st, n_rows, w.drow_b, w.rank);
+  HIP_TRY(hipGetLastError());
+  // merged column list of every group
+  hipLaunchKernelGGL(k_tg_entry_keys, blocks_for(nnz), dim3(T), 0, st, n_rows, nnz, rowptr, colidx, w.rank, cbits,
+                     w.keys_a);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.keys_a, w.keys_b, size_t(nnz), 0u, unsigned(9 + cbits + gbits), st));
+  hipLaunchKernelGGL(k_tg_heads, blocks_for(nnz), dim3(T), 0, st, nnz, w.keys_b, 9, w.head);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.head, w.pos, 0u, size_t(nnz), rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_tg_merged, blocks_for(nnz), dim3(T), 0, st, w.G, nnz, w.keys_b, w.head, w.pos, cbits, w.mcol,
+                     w.gptr, w.counts);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tg_group_stages, blocks_for(w.G + 1), dim3(T), 0, st, w.G, w.gptr, w.gns);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.gns, w.gstage0, 0u, size_t(w.G + 1), rocprim::plus<uint32_t>(), st));
+  // per (stage, sub-tile): its columns, packed 16 to a step
+  hipLaunchKernelGGL(k_tg_step_keys, blocks_for(nnz), dim3(T), 0, st, nnz, w.keys_b, w.head, w.pos, w.gptr, w.gstage0, cbits,
+                     w.keys_a);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.keys_a, w.keys_b, size_t(nnz), 0u, unsigned(5 + kSlotBits + rbits), st));
+  hipLaunchKernelGGL(k_tg_heads, blocks_for(nnz), dim3(T), 0, st, nnz, w.keys_b, 5, w.head);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.head, w.pos, 0u, size_t(nnz), rocprim::plus<uint32_t>(), st));
+  HIP_TRY(hipMemsetAsync(w.runcount, 0, size_t(w.cap_runs + 1) * 4, st));
+  hipLaunchKernelGGL(k_tg_run_counts, blocks_for(nnz), dim3(T), 0, st, nnz, w.keys_b, w.head, w.pos, w.runcount,
+                     w.runfirst);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tg_run_steps, blocks_for(w.cap_runs + 1), dim3(T), 0, st, w.cap_runs, w.counts, w.gstage0, w.G,
+                     w.runcount, w.nsteps);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.nsteps, w.step0, 0u, size_t(w.cap_runs + 1), rocprim::plus<uint32_t>(),
+                                  st));
+  // work items
+  const int seg = g_seg_stages;
+  hipLaunchKernelGGL(k_tg_nseg, blocks_for(w.G), dim3(T), 0, st, w.G, seg, w.gns, w.nseg, w.lseg, w.lflag);
+  HIP_TRY(hipGetLastError());
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.nseg, w.first, 0u, size_t(w.G), rocprim::plus<uint32_t>(), st));
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lseg, w.slot0, 0u, size_t(w.G), rocprim::plus<uint32_t>(), st));
+  pb = w.prim_bytes;
+  HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lflag, w.lidx, 0u, size_t(w.G), rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_tg_totals, dim3(1), dim3(64), 0, st, w.G, w.gstage0, w.step0, w.nseg, w.first, w.lseg, w.slot0,
+                     w.lflag, w.lidx, seg, w.counts);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t stages, int64_t steps, int64_t items,
+                        int64_t long_groups, void* plan, size_t plan_bytes, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_rows <= 0 || n_cols <= 0 || nnz <= 0) return fail(SGNN_ERR_INVALID, "empty matrix");
+  if (!plan || !workspace) return fail(SGNN_ERR_INVALID, "null pointer");
+  TgBuild w = carve_tg_build(workspace, n_rows, nnz);
+  if (workspace_bytes < w.total) return fail(SGNN_ERR_WORKSPACE, "tile-group build workspace too small");
+  if (stages <= 0 || stages > w.cap_stages || steps <= 0 || items <= 0 || items > w.cap_items || long_groups < 0 ||
+      long_groups > w.G)
+    return fail(SGNN_ERR_INVALID, "counts do not match the analysed matrix");
+  TgPlan p = carve_tg_plan(plan, n_rows, stages, steps, items, long_groups);
+  if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "tile-group plan buffer too small");
+  const unsigned T = 256;
+  HIP_TRY(hipMemcpyAsync(p.counts, w.counts, 64, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_tg_grows, blocks_for(p.G * kRows), dim3(T), 0, st, n_rows, p.G * kRows, w.drow_b, p.grows);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tg_copy_u32, blocks_for(p.G + 1), dim3(T), 0, st, p.G + 1, w.gstage0, p.gstage0, p.G + 1);
+  HIP_TRY(hipGetLastError());
+  const int64_t runs = stages * kSubs;
+  hipLaunchKernelGGL(k_tg_copy_u32, blocks_for(runs + 1 + 128), dim3(T), 0, st, runs + 1, w.step0, p.step0,
+                     runs + 1 + 128);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(p.stage_col + stages * kStageCols, 0, kStageCols * 4, st));
+  hipLaunchKernelGGL(k_tg_stage_cols, blocks_for(stages * kStageCols), dim3(T), 0, st, p.G, stages, w.gptr, w.gstage0,
+                     w.mcol, p.stage_col);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(p.step_slots, 0, size_t(steps + kPadSteps) * 32, st));
+  HIP_TRY(hipMemsetAsync(p.step_bits, 0, size_t(steps + kPadSteps) * 64, st));
+  hipLaunchKernelGGL(k_tg_fill_steps, blocks_for(nnz), dim3(T), 0, st, nnz, w.keys_b, w.head, w.pos, w.runfirst,
+                     w.step0, p.step_slots, reinterpret_cast<uint32_t*>(p.step_bits));
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tg_items, blocks_for(p.G), dim3(T), 0, st, p.G, w.gns, w.gstage0, w.nseg, w.first, w.slot0,
+                     w.lidx, w.itmp, w.cap_items, p.long_group, p.long_slot, p.long_nseg);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tg_item_keys, blocks_for(items), dim3(T), 0, st, items, w.itmp, w.cap_items, p.stage_col,
+                     g_order_cols, w.ikey_a);
+  HIP_TRY(hipGetLastError());
+  size_t pb = w.prim_bytes;
+  HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.ikey_a, w.ikey_b, size_t(items), 0u, 64u, st));
+  hipLaunchKernelGGL(k_tg_item_place, blocks_for(items), dim3(T), 0, st, items, w.ikey_b, w.itmp, w.cap_items,
+                     p.item_group, p.item_s0, p.item_s1, p.item_out);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+size_t sgnn_tilegroup_planes_bytes(int64_t n_cols, int64_t F) {
+  if (n_cols <= 0 || F <= 0) return 0;
+  const int64_t slices = (F + kSlice - 1) / kSlice;
+  return align_up(size_t(slices) * size_t(n_cols) * kRowBytes + 256);
+}
+
+int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, const float* X, int64_t ldx,
+                             void* planes, size_t planes_bytes, void* state, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_cols <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty operand");
+  if (!X || !planes || !state) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (ldx < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
+  if (planes_bytes < sgnn_tilegroup_planes_bytes(n_cols, F)) return fail(SGNN_ERR_WORKSPACE, "planes buffer too small");
+  if (reinterpret_cast<uintptr_t>(planes) % 16) return fail(SGNN_ERR_INVALID, "planes must be 16-byte aligned");
+  const int64_t slices = (F + kSlice - 1) / kSlice;
+  TgState* s = static_cast<TgState*>(state);
+  HIP_TRY(hipMemsetAsync(s, 0, sizeof(TgState), st));
+  hipLaunchKernelGGL(k_tg_amax, dim3(2048), dim3(256), 0, st, n_cols, F, scale_row, X, ldx, s);
+  HIP_TRY(hipGetLastError());
+  const int64_t threads = n_cols * slices * (kSlice / 8);
+  hipLaunchKernelGGL(k_tg_split, blocks_for(threads), dim3(256), 0, st, n_cols, F, slices, scale_row, X, ldx,
+                     static_cast<char*>(planes), s);
+  HIP_TRY(hipGetLastError());
+  const int64_t lim = (n_cols * F) >> 20;
+  hipLaunchKernelGGL(k_tg_finish, dim3(1), dim3(1), 0, st, s, uint32_t(lim > 16 ? lim : 16));
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F) {
+  if (partial_slots < 0 || F <= 0) return 0;
+  const int64_t Fpad = (F + kSlice - 1) / kSlice * kSlice;
+  return align_up(size_t(partial_slots) * kRows * size_t(Fpad) * 4 + 256);
+}
+
+int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
+                            int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
+                            const float* dinv_row, float w_off, const void* planes, size_t planes_bytes,
+                            const void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                            size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                            const float* vals, const float* dinv_col, const float* X, int64_t ldx,
+                            void* csr_workspace, size_t csr_workspace_bytes, void* stream) {
+  if (n_rows <= 0 || n_cols <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty problem");
+  if (!plan || !planes || !state || !Y) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (ldy < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
+  if (epilogue != SGNN_EPI_SCALE_ROW && epilogue != SGNN_EPI_SCALE_ROW2)
+    return fail(SGNN_ERR_INVALID, "unknown epilogue mode");
+  if (stages <= 0 || steps <= 0 || items <= 0 || partial_slots < 0 || long_groups < 0)
+    return fail(SGNN_ERR_INVALID, "counts do not match the plan");
+  TgPlan p = carve_tg_plan(const_cast<void*>(plan), n_rows, stages, steps, items, long_groups);
+  if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "tile-group plan buffer too small");
+  if (planes_bytes < sgnn_tilegroup_planes_bytes(n_cols, F)) return fail(SGNN_ERR_WORKSPACE, "planes buffer too small");
+  if (partial_slots > 0 && (!workspace || workspace_bytes < sgnn_spmm_tilegroup_workspace_bytes(partial_slots, F)))
+    return fail(SGNN_ERR_WORKSPACE, "tile-group spmm workspace too small");
+  const int64_t slices = (F + kSlice - 1) / kSlice;
+  if (slices > 65535) return fail(SGNN_ERR_INVALID, "too many feature slices for one launch");
+  TgArgs a{};
+  a.grows = p.grows; a.stage_col = p.stage_col; a.step0 = p.step0;
+  a.step_slots = p.step_slots; a.step_bits = p.step_bits;
+  a.item_group = p.item_group; a.item_s0 = p.item_s0; a.item_s1 = p.item_s1; a.item_out = p.item_out;
+  a.long_group = p.long_group; a.long_slot = p.long_slot; a.long_nseg = p.long_nseg;
+  a.planes = static_cast<const char*>(planes);
+  a.state = static_cast<const TgState*>(state);
+  a.dinv_row = dinv_row; a.Y = Y; a.partial = static_cast<float*>(workspace);
+  a.ldy = ldy; a.slice_bytes = n_cols * kRowBytes;
+  a.items = int32_t(items); a.n_long = int32_t(long_groups);
+  a.F = int32_t(F); a.Fpad = int32_t(slices * kSlice); a.epilogue = epilogue; a.w_off = w_off;
+  a.mode = g_tg_mode;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tg_spmm<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_tg_spmm<4>), dim3(unsigned(items), unsigned(slices)), dim3(kWaves * kWave), kLdsBytes, st, a);
+  HIP_TRY(hipGetLastError());
+  if (long_groups > 0) {
+    hipLaunchKernelGGL(k_tg_combine, dim3(unsigned(long_groups), 64), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+  }
+  if (rowptr != nullptr) {
+    // fall-back for an X the planes cannot represent: the plain CSR kernel on the original
+    // operand, behind the same flag (its kernels return at once while the flag is 0)
+    if (!colidx || !X) return fail(SGNN_ERR_INVALID, "null pointer");
+    return spmm_csr_guarded(n_rows, n_cols, nnz, F, rowptr, colidx, vals, dinv_row, dinv_col, X, ldx, Y, ldy, epilogue,
+                            csr_workspace, csr_workspace_bytes, &static_cast<const TgState*>(state)->flag, st);
+  }
+  return SGNN_OK;
+}
+
+}  // extern "C"

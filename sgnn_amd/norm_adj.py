@@ -90,6 +90,11 @@ class NormAdj:
         self._ws = {}
         self._plans = {}                  # R -> row-group plan (built on first use)
         self.use_rowgroup = True          # uniform-weight graphs, supported widths: see _rowgroup_plan
+        # tile-group (matrix-core) kernel: None = used where the graph's rows share enough
+        # columns to pay for it (see _tilegroup_plan), True / False force it on / off
+        self.use_tilegroup = None
+        self._tg = None                   # its plan; False once it has been found not worthwhile
+        self._tg_bufs = {}
 
     @property
     def vals(self):
@@ -238,6 +243,67 @@ class NormAdj:
             self._plans[R] = plan
         return plan
 
+    # a fetched row of X must serve at least this many stored entries, on average over the
+    # groups of 512 rows, for the tile-group kernel to be chosen automatically
+    TILEGROUP_MIN_SHARING = 4.0
+
+    def _tilegroup_plan(self, F):
+        """Tile-group plan, or None when that kernel does not apply (weights that differ,
+        a diagonal of its own, narrow features, rows that share too few columns, switched off)."""
+        if self.use_tilegroup is False or not self.use_rowgroup or self.nnz == 0:
+            return None
+        if self.w_off is None or self.corr is not None:
+            return None
+        auto = self.use_tilegroup is None
+        if auto and (F < 96 or self.n < 8192 or self.nnz < 32 * self.n):
+            return None
+        if self._tg is None:
+            lib = _lib.load()
+            with torch.cuda.device(self.device):
+                st = _lib.current_stream(self.device)
+                wbytes = lib.sgnn_tilegroup_build_workspace_bytes(self.n, self.nnz)
+                ws = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
+                _lib.check(lib.sgnn_tilegroup_analyze(self.n, self.n, self.nnz, _lib.ptr(self.rowptr),
+                                                      _lib.ptr(self.colidx), _lib.ptr(ws), wbytes, st))
+                merged, stages, steps, items, slots, n_long = (int(v) for v in ws[:48].view(torch.int64).cpu())
+                if auto and merged * self.TILEGROUP_MIN_SHARING > self.nnz:
+                    self._tg = False
+                else:
+                    pbytes = lib.sgnn_tilegroup_plan_bytes(self.n, stages, steps, items, n_long)
+                    buf = torch.empty(pbytes, dtype=torch.uint8, device=self.device)
+                    _lib.check(lib.sgnn_tilegroup_fill(self.n, self.n, self.nnz, stages, steps, items, n_long,
+                                                       _lib.ptr(buf), pbytes, _lib.ptr(ws), wbytes, st))
+                    torch.cuda.current_stream(self.device).synchronize()      # the workspace goes away below
+                    self._tg = dict(buf=buf, bytes=pbytes, merged=merged, stages=stages, steps=steps, items=items,
+                                    slots=slots, n_long=n_long)
+                del ws
+        return self._tg or None
+
+    def _tilegroup_hop(self, plan, X, ldx, Y, ldy, F, scale_rows, scale_cols, epilogue):
+        """One hop through the tile-group kernel: split X (times dinv per row if ``scale_cols``)
+        into fp16 planes, multiply; the plain CSR kernel stands behind it for operands the
+        planes cannot represent."""
+        lib = _lib.load()
+        bufs = self._tg_bufs.get(F)
+        if bufs is None:
+            pl_bytes = lib.sgnn_tilegroup_planes_bytes(self.n, F)
+            ws_bytes = lib.sgnn_spmm_tilegroup_workspace_bytes(plan["slots"], F)
+            bufs = dict(planes=torch.empty(pl_bytes, dtype=torch.uint8, device=self.device), pl_bytes=pl_bytes,
+                        ws=torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=self.device),
+                        state=torch.zeros(64, dtype=torch.int32, device=self.device))
+            self._tg_bufs = {F: bufs}
+        csr_ws = self._workspace(F)
+        st = _lib.current_stream(self.device)
+        dinv = _lib.ptr(self.dinv)
+        _lib.check(lib.sgnn_tilegroup_split_f32(self.n, F, dinv if scale_cols else None, _lib.ptr(X), ldx,
+                                                _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), st))
+        _lib.check(lib.sgnn_spmm_tilegroup_f32(
+            self.n, self.n, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"],
+            plan["slots"], plan["n_long"], dinv if scale_rows else None, float(self.w_off),
+            _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), _lib.ptr(Y), ldy, int(epilogue),
+            _lib.ptr(bufs["ws"]), bufs["ws"].numel(), self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
+            _lib.ptr(self._vals), dinv if scale_cols else None, _lib.ptr(X), ldx, _lib.ptr(csr_ws), csr_ws.numel(), st))
+
     def _rowgroup_ws(self, plan, F):
         ws = plan["ws"].get(F)
         if ws is None:
@@ -295,6 +361,10 @@ class NormAdj:
             if F == 0:
                 return Y
             ldx = X.stride(0) if X.shape[0] > 1 else F
+            tg = self._tilegroup_plan(F)
+            if tg is not None:
+                self._tilegroup_hop(tg, X, ldx, Y, Y.stride(0) if self.n > 1 else F, F, scale_rows, scale_cols, epilogue)
+                return Y
             if self._rowgroup_plan(F) is not None and (scale_cols or X.data_ptr() % 16 or ldx % 4):
                 # stage X for the row-group kernel: column scaling applied (utils.py:93),
                 # rows on 16-byte boundaries
@@ -327,6 +397,19 @@ class NormAdj:
         with torch.cuda.device(self.device):
             Y = torch.empty((self.n, F), dtype=torch.float32, device=self.device)
             if F == 0:
+                return Y
+            tg = self._tilegroup_plan(F)
+            if tg is not None:
+                # tile-group kernel: the split pass applies utils.py:93 on the first hop; later
+                # hops read what the previous epilogue already scaled twice
+                src, lds = X, (X.stride(0) if X.shape[0] > 1 else F)
+                spare = [torch.empty((self.n, F), dtype=torch.float32, device=self.device) for _ in range(min(order - 1, 2))]
+                for h in range(order):
+                    last = h == order - 1
+                    dst = Y if last else spare[h % 2]
+                    self._tilegroup_hop(tg, src, lds, dst, F, F, True, h == 0,
+                                        _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2)
+                    src, lds = dst, F
                 return Y
             if self._rowgroup_plan(F) is None:
                 # plain CSR kernel: the library's own K-hop chain

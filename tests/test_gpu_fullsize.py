@@ -1,7 +1,8 @@
 """Full-size checks on the benchmark shapes, through properties that need no CPU
 reference of that size:
 
-* the two independent kernels (plain CSR, row-group) agree to fp32 rounding;
+* the three independent kernels (plain CSR, row-group, tile-group on the matrix cores) agree
+  to fp32 rounding;
 * A_hat . D^1/2 1 = D^1/2 1;  linearity;  the weighted checksum
   (D^1/2 1)^T A_hat X = (D^1/2 1)^T X  (symmetric A);
 * K hops as one chain equal K single hops;
@@ -36,15 +37,22 @@ def test_reddit_shape_full_size_properties(gpu_device):
     g = torch.Generator(device=dev); g.manual_seed(3)
     X = torch.randn(n, F, device=dev, generator=g)
     adj.use_rowgroup = True
+    Y_tg = adj.propagate(X, 1)                   # this shape is what the tile-group kernel is chosen for
+    assert adj._tg, "tile-group plan was not used"
+    assert int(adj._tg_bufs[F]["state"][1].item()) == 0, "the fp16 planes refused ordinary data"
+    adj.use_tilegroup = False
     Y_rg = adj.propagate(X, 1)
     assert adj._plans, "row-group plan was not used"
     adj.use_rowgroup = False
     Y_csr = adj.propagate(X, 1)
-    assert float((Y_rg - Y_csr).norm() / Y_csr.norm()) <= TOL
     # element-wise against |A_hat| |X|
     scale = adj.propagate(X.abs(), 1)
-    assert float(((Y_rg - Y_csr).abs() / scale).max()) <= TOL
+    for Y in (Y_rg, Y_tg):
+        assert float((Y - Y_csr).norm() / Y_csr.norm()) <= TOL
+        assert float(((Y - Y_csr).abs() / scale).max()) <= TOL
     adj.use_rowgroup = True
+    adj.use_tilegroup = None
+    Y_rg = Y_tg                                  # the properties below are checked on the kernel the benchmark runs
     s = adj.deg.sqrt()
     fixed = adj.propagate(s[:, None].expand(n, 64).contiguous(), 1)
     assert float(((fixed - s[:, None]).abs() / s[:, None]).max()) <= TOL

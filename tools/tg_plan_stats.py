@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Work balance of a tile-group plan (run on the GPU box): steps per wavefront and stage."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sgnn_amd import NormAdj  # noqa: E402
+from sgnn_amd.graphgen import SHAPES, rmat_undirected_device  # noqa: E402
+
+dev = torch.device("cuda:0")
+wl = sys.argv[1] if len(sys.argv) > 1 else "reddit"
+n, E, F = SHAPES[wl]
+row, col = rmat_undirected_device(n, E, seed=1, device=dev)
+adj = NormAdj.from_coo(row, col, None, n, dev)
+del row, col
+adj.use_tilegroup = True
+p = adj._tilegroup_plan(F)
+al = lambda x: (x + 255) // 256 * 256
+G = (n + 511) // 512
+stages, steps = p["stages"], p["steps"]
+off = al(64) + al(G * 512 * 4) + al((G + 1) * 4) + al((stages * 128 + 128) * 4)
+step0 = p["buf"][off: off + (stages * 16 + 1) * 4].view(torch.int32).long()
+per = (step0[1:] - step0[:-1]).view(stages, 16)                     # steps of (stage, sub-tile)
+print("steps per (stage, sub-tile): mean %.2f" % per.float().mean().item(), "hist", torch.bincount(per.flatten(), minlength=9).tolist())
+wave = per[:, :8] + per[:, 8:].flip(1)                               # wavefront w: sub-tiles w and 15 - w
+wave_old = per[:, :8] + per[:, 8:]
+for name, wv in (("w,15-w", wave), ("w,w+8", wave_old)):
+    mx, mean = wv.max(1).values.float(), wv.float().mean(1)
+    print(f"{name}: steps per wavefront and stage mean {mean.mean():.2f}; sum of max over stages {mx.sum():.0f} "
+          f"vs sum of mean {mean.sum():.0f}: imbalance {mx.sum() / mean.sum():.3f}")
+print("sub-tile mean steps by position in group:", [round(v, 2) for v in per.float().mean(0).tolist()])
+tot = per.sum(1).float()
+print("steps per stage: mean %.1f min %d max %d" % (tot.mean().item(), tot.min().item(), tot.max().item()))
