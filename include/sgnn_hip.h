@@ -207,6 +207,10 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           sgnn_spmm_workspace_bytes); rowptr == NULL: no fall-back is
  *                           launched and Y is left untouched when state's flag is set.
  */
+/* Diagnostics: cycle counters of tile-group runs made with tuning key "tg_mode" bit 16 set (kernel,
+ * stage waits, next-stage issue, step loops, wavefronts, steps, stages; summed over wavefronts);
+ * reading clears them.  No counterpart in the reference. */
+int sgnn_tilegroup_debug_counters(unsigned long long* out8);
 size_t sgnn_tilegroup_build_workspace_bytes(int64_t n_rows, int64_t nnz);
 size_t sgnn_tilegroup_plan_bytes(int64_t n_rows, int64_t stages, int64_t steps, int64_t items, int64_t long_groups);
 int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,

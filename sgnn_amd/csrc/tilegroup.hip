@@ -63,10 +63,11 @@ constexpr int kStageRowsBytes = kStageCols * kRowBytes;
 constexpr int kMaxStageSteps = kSubs * (kStageCols / kStepCols);   // 128
 constexpr int kSlotsBytes = kMaxStageSteps * 32;
 constexpr int kBitsBytes = kMaxStageSteps * 64;
-constexpr int kHdrBytes = 512;
-constexpr int kStageBytes = kStageRowsBytes + kSlotsBytes + kBitsBytes + kHdrBytes;   // 78336 = 153 * 512
-constexpr int kTableBytes = 128;
-constexpr int kLdsBytes = kRing * kStageBytes + kTableBytes;
+constexpr int kHdrBytes = 512;                   // first steps of this stage's and the next stages' sub-tiles
+constexpr int kColsBytes = 1024;                 // column ids of the next two stages
+constexpr int kStageBytes = kStageRowsBytes + kSlotsBytes + kBitsBytes + kHdrBytes + kColsBytes;   // 79360 = 155 * 512
+constexpr int kTableBytes = 512;                 // pattern table at LDS offset 0; the stage buffers follow, 512-byte aligned
+constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;
 constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slack behind the step arrays (a stage's DMA over-reads)
 static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wavefront loads 16 rows of a stage");
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
@@ -106,7 +107,7 @@ TgPlan carve_tg_plan(void* base, int64_t n_rows, int64_t stages, int64_t steps, 
   p.counts = c.take<int64_t>(8);
   p.grows = c.take<int32_t>(size_t(p.G) * kRows);
   p.gstage0 = c.take<int32_t>(size_t(p.G) + 1);
-  p.stage_col = c.take<int32_t>(size_t(stages) * kStageCols + kStageCols);
+  p.stage_col = c.take<int32_t>(size_t(stages) * kStageCols + 3 * kStageCols);   // a stage's DMA also brings the next two stages' ids
   p.step0 = c.take<int32_t>(size_t(stages) * kSubs + 1 + 128);   // the header DMA of the last stage reads 64 entries
   p.step_slots = c.take<uint16_t>(size_t(steps + kPadSteps) * 16);
   p.step_bits = c.take<uint16_t>(size_t(steps + kPadSteps) * 32);
@@ -489,6 +490,10 @@ __global__ void k_tg_finish(TgState* __restrict__ state, uint32_t tiny_limit) {
   if (state->tiny > tiny_limit) atomicOr(&state->flag, 2u);
 }
 
+// cycle counts of a diagnostic run (mode bit 16): kernel, waits for a stage, issue of the next
+// stage, step loops; wavefronts that took part; steps
+__device__ unsigned long long g_tg_dbg[8];
+
 // ---- the kernel -----------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -526,7 +531,7 @@ __device__ __forceinline__ void tg_dma4(const void* g, uint32_t lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
 }
 
-// One workgroup per (work item, feature slice); 8 wavefronts, wavefront w owns sub-tiles w and 15 - w.
+// One workgroup per (work item, feature slice); 8 wavefronts, wavefront w owns sub-tiles 2 w and 2 w + 1.
 template <int NT>
 __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -538,11 +543,17 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   const uint32_t lds0 = uint32_t(uintptr_t((__attribute__((address_space(3))) char*)smem));
   const char* xs = a.planes + int64_t(slice) * a.slice_bytes;
 
-  // pattern tile from a nibble of row bits: two dwords of fp16 pairs, 1.0 where the bit is set
-  uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + kRing * kStageBytes);
+  // Pattern table at LDS offset 0: entry v (a nibble of row bits) holds two dwords of fp16
+  // pairs with 1.0 where the bit is set (hi plane), then the same with 2^-11 (lo plane, which
+  // holds the remainder times 2048).
+  uint32_t* tbl = reinterpret_cast<uint32_t*>(smem);
   if (tid < 16) {
-    tbl[2 * tid] = ((tid & 1) ? 0x3C00u : 0u) | ((tid & 2) ? 0x3C000000u : 0u);
-    tbl[2 * tid + 1] = ((tid & 4) ? 0x3C00u : 0u) | ((tid & 8) ? 0x3C000000u : 0u);
+    const uint32_t d0 = ((tid & 1) ? 0x3C00u : 0u) | ((tid & 2) ? 0x3C000000u : 0u);
+    const uint32_t d1 = ((tid & 4) ? 0x3C00u : 0u) | ((tid & 8) ? 0x3C000000u : 0u);
+    tbl[4 * tid] = d0;
+    tbl[4 * tid + 1] = d1;
+    tbl[4 * tid + 2] = d0 & 0x10001000u;
+    tbl[4 * tid + 3] = d1 & 0x10001000u;
   }
 
   f32x16 acc[2][NT];
@@ -566,37 +577,21 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   const uint32_t swz_odd = (((pc >> 2) ^ uint32_t(2 + h)) << 6) | ((pc & 3u) << 4);
   const bool small = a.slice_bytes < (int64_t(1) << 32);   // row offsets fit 32 bits
 
-  // A stage's column ids and first step are wave-uniform and read through the constant
-  // address space, i.e. by scalar loads: a vector load here would enter the vmcnt queue
-  // in front of the DMAs.
-  typedef int i32x16 __attribute__((ext_vector_type(16)));
-  typedef const __attribute__((address_space(4))) i32x16* c16ptr;
-  typedef const __attribute__((address_space(4))) int32_t* c1ptr;
-  auto stage_cols = [&](int s) {
-    return *reinterpret_cast<c16ptr>(uintptr_t(a.stage_col + int64_t(s) * kStageCols + w * 16));
-  };
-  auto stage_first_step = [&](int s) {
-    return *reinterpret_cast<c1ptr>(uintptr_t(a.step0 + int64_t(s) * kSubs));
-  };
-  // Stage s into ring buffer (s - s0) % 2: wavefront w brings rows 16 w .. 16 w + 15 (two per
-  // instruction) and a share of the stage's step records.
-  auto issue = [&](int s, i32x16 cols, int sf32) {
-    const uint32_t buf = lds0 + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
+  // Stage s into ring buffer (s - s0) % 2.  Wavefront w brings rows 16 w .. 16 w + 15 (two per
+  // instruction; `col[i]` is the column of row 16 w + 2 i + h for this lane's half h) and a share
+  // of the stage's records: the steps' row offsets and row bits (only as many kilobytes as
+  // the stage has steps), the first-step table from this stage on, and the column ids of the
+  // following stages, so that the next stage is issued from LDS and not from scalar loads
+  // whose latency every wavefront would sit out once per stage.
+  auto issue = [&](int s, const int (&col)[8], int sf32, int steps) {
+    const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
     if (!(a.mode & 2)) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        // (kept as two scalar values: written as one select of vector elements the compiler
-        // turns it into a lane-indexed element access, a chain of 16 compares per row)
-        const uint32_t c_even = uint32_t(__builtin_amdgcn_readfirstlane(cols[2 * i]));
-        const uint32_t c_odd = uint32_t(__builtin_amdgcn_readfirstlane(cols[2 * i + 1]));
         const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(8 * w + i) * 1024u);
-        if (small) {
-          const uint32_t off = (h ? c_odd * uint32_t(kRowBytes) : c_even * uint32_t(kRowBytes)) | ((i & 1) ? swz_odd : swz_even);
-          tg_dma16_off(xs, off, dst);
-        } else {
-          const int64_t col = h ? c_odd : c_even;
-          tg_dma16(xs + col * kRowBytes + ((i & 1) ? swz_odd : swz_even), dst);
-        }
+        const uint32_t swz = (i & 1) ? swz_odd : swz_even;
+        if (small) tg_dma16_off(xs, (uint32_t(col[i]) << 9) | swz, dst);
+        else tg_dma16(xs + int64_t(col[i]) * kRowBytes + swz, dst);
       }
     }
     const int64_t sf = sf32;
@@ -604,56 +599,91 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     if (w >= 6) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        tg_dma16(reinterpret_cast<const char*>(a.step_slots) + sf * 32 + ((w - 6) * 2 + i) * 1024 + lane * 16,
-                 __builtin_amdgcn_readfirstlane(rec + uint32_t((w - 6) * 2 + i) * 1024u));
+        if (((w - 6) * 2 + i) * 32 < steps)
+          tg_dma16(reinterpret_cast<const char*>(a.step_slots) + sf * 32 + ((w - 6) * 2 + i) * 1024 + lane * 16,
+                   __builtin_amdgcn_readfirstlane(rec + uint32_t((w - 6) * 2 + i) * 1024u));
     } else if (w >= 1 && w <= 4) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        tg_dma16(reinterpret_cast<const char*>(a.step_bits) + sf * 64 + ((w - 1) * 2 + i) * 1024 + lane * 16,
-                 __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + uint32_t((w - 1) * 2 + i) * 1024u));
+        if (((w - 1) * 2 + i) * 16 < steps)
+          tg_dma16(reinterpret_cast<const char*>(a.step_bits) + sf * 64 + ((w - 1) * 2 + i) * 1024 + lane * 16,
+                   __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + uint32_t((w - 1) * 2 + i) * 1024u));
     } else if (w == 5) {
       tg_dma4(a.step0 + int64_t(s) * kSubs + lane, __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + kBitsBytes));
+    } else {
+      tg_dma16(a.stage_col + (int64_t(s) + 1) * kStageCols + lane * 4,
+               __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + kBitsBytes + kHdrBytes));
     }
   };
 
+  const bool dbg = (a.mode & 16) != 0;
+  unsigned long long t_wait = 0, t_issue = 0, t_steps = 0, n_steps = 0;
+  const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
   const int ns = s1 - s0;
-  const int last = s1 - 1;
-  if (ns > 0) issue(s0, stage_cols(s0), stage_first_step(s0));
-  // ids of the stage issued in the next iteration, fetched one iteration early
-  i32x16 ncols = stage_cols(min(s0 + 1, last));
-  int nsf = stage_first_step(min(s0 + 1, last));
+  if (ns > 0) {   // the item's first stage: ids by scalar loads (constant address space)
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef const __attribute__((address_space(4))) i32x16* c16ptr;
+    typedef const __attribute__((address_space(4))) int32_t* c1ptr;
+    const i32x16 cols = *reinterpret_cast<c16ptr>(uintptr_t(a.stage_col + int64_t(s0) * kStageCols + w * 16));
+    const int sf_first = *reinterpret_cast<c1ptr>(uintptr_t(a.step0 + int64_t(s0) * kSubs));
+    const int sf_second = *reinterpret_cast<c1ptr>(uintptr_t(a.step0 + (int64_t(s0) + 1) * kSubs));
+    int col[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      // (two scalar values and a select: written as a select of vector elements the compiler
+      // makes it a lane-indexed element access, a chain of 16 compares)
+      const int c_even = __builtin_amdgcn_readfirstlane(cols[2 * i]), c_odd = __builtin_amdgcn_readfirstlane(cols[2 * i + 1]);
+      col[i] = h ? c_odd : c_even;
+    }
+    issue(s0, col, sf_first, sf_second - sf_first);
+  }
 
   for (int k = 0; k < ns; ++k) {
+    const unsigned long long t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of stage k has landed
     __builtin_amdgcn_s_barrier();                      // everyone's has; stage k - 1 is no longer read
     asm volatile("" ::: "memory");
-    if (k + 1 < ns) issue(s0 + k + 1, ncols, nsf);
-    ncols = stage_cols(min(s0 + k + 2, last));
-    nsf = stage_first_step(min(s0 + k + 2, last));
+    const unsigned long long t1 = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
-    const uint32_t boff = uint32_t(k & (kRing - 1)) * kStageBytes;
+    const uint32_t boff = kTableBytes + uint32_t(k & (kRing - 1)) * kStageBytes;
     const int* hdr = reinterpret_cast<const int*>(smem + boff + kStageRowsBytes + kSlotsBytes + kBitsBytes);
-    const int sf = __builtin_amdgcn_readfirstlane(hdr[0]);
-    // this wavefront's steps of the stage: those of sub-tile w, then those of sub-tile 15 - w
-    // (rows are ranked by degree, so the two lists together are about equally long for every w)
-    const int b0 = __builtin_amdgcn_readfirstlane(hdr[w]) - sf;
-    const int n0 = __builtin_amdgcn_readfirstlane(hdr[w + 1]) - sf - b0;
-    const int b1 = __builtin_amdgcn_readfirstlane(hdr[kSubs - 1 - w]) - sf;
-    const int total = n0 + __builtin_amdgcn_readfirstlane(hdr[kSubs - w]) - sf - b1;
-
-    // A step's record as this lane needs it: the LDS offsets of the two rows it addresses
-    // in the transposed reads, and its 8 row bits.
-    auto record = [&](int j, uint32_t& off_a, uint32_t& off_b, uint32_t& bt) {
-      const uint32_t ls = uint32_t(j < n0 ? b0 + j : b1 + (j - n0));
-      const char* o = smem + boff + offs_off + ls * 32;
-      off_a = *reinterpret_cast<const uint16_t*>(o);
-      off_b = *reinterpret_cast<const uint16_t*>(o + 8);
-      bt = *reinterpret_cast<const uint8_t*>(smem + boff + bits_off + ls * 64);
+    // The next stage is issued from the ids this stage's image carries, by every wavefront
+    // before its steps (taking turns between the two wavefronts of a SIMD, or spreading the
+    // issue between the steps, measured slower: the CU's memory pipeline takes ~1400 cycles
+    // to accept a stage either way and the earlier it starts the earlier the rows arrive).
+    auto issue_next = [&]() {
+      const int* nc = hdr + kHdrBytes / 4 + 16 * w + h;
+      int col[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) col[i] = nc[2 * i];
+      const int nsf = __builtin_amdgcn_readfirstlane(hdr[kSubs]);
+      issue(s0 + k + 1, col, nsf, __builtin_amdgcn_readfirstlane(hdr[2 * kSubs]) - nsf);
     };
-    auto pattern = [&](uint32_t bt) {
-      const uint2 t0 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tbl) + (bt & 15u) * 8u);
-      const uint2 t1 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tbl) + (bt >> 4) * 8u);
-      return u32x4{t0.x, t0.y, t1.x, t1.y};
+    if (k + 1 < ns) issue_next();
+    const int sf = __builtin_amdgcn_readfirstlane(hdr[0]);
+    const unsigned long long t2 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    // this wavefront's steps of the stage: those of sub-tile 2 w, then those of sub-tile 2 w + 1,
+    // one contiguous run of records
+    const int b0 = __builtin_amdgcn_readfirstlane(hdr[2 * w]) - sf;
+    const int n0 = __builtin_amdgcn_readfirstlane(hdr[2 * w + 1]) - sf - b0;
+    const int total = __builtin_amdgcn_readfirstlane(hdr[2 * w + 2]) - sf - b0;
+    const uint32_t stage_lane = boff + lane_off;
+    // A step's record as this lane needs it: the LDS offsets of the two rows it addresses in
+    // the transposed reads, and its 8 row bits.  Reading past the wavefront's last record is
+    // harmless (the bytes are inside the stage buffer, what is read is not used).
+    uint32_t rec_o = boff + offs_off + uint32_t(b0) * 32u, rec_b = boff + bits_off + uint32_t(b0) * 64u;
+    auto record = [&](uint32_t& off_a, uint32_t& off_b, uint32_t& bt) {
+      off_a = *reinterpret_cast<const uint16_t*>(smem + rec_o);
+      off_b = *reinterpret_cast<const uint16_t*>(smem + rec_o + 8);
+      bt = *reinterpret_cast<const uint8_t*>(smem + rec_b);
+      rec_o += 32;
+      rec_b += 64;
+    };
+    auto pattern = [&](uint32_t bt, u32x4& hi, u32x4& lo) {
+      const u32x4 t0 = *reinterpret_cast<const u32x4*>(smem + (bt & 15u) * 16u);
+      const u32x4 t1 = *reinterpret_cast<const u32x4*>(smem + (bt & 0xF0u));
+      hi = u32x4{t0[0], t0[1], t1[0], t1[1]};
+      lo = u32x4{t0[2], t0[3], t1[2], t1[3]};
     };
     auto read_tile = [&](uint32_t base_a, uint32_t base_b, int pl, int nt) {
       const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
@@ -671,33 +701,33 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     // Software pipeline over the steps.  Behind every MFMA of step j the reads of the same tile
     // of X for step j + 1 go out into the registers that MFMA has just consumed, so a read has
     // seven MFMAs of this wavefront (and the other wavefront's on the SIMD) to arrive; the
-    // record of step j + 2 and the pattern tile of step j + 1 are fetched at the top.  The
-    // last steps prefetch the final step again: no branches in the body.  One loop per
-    // sub-tile, so that the accumulators are addressed statically; the prefetch runs across
-    // the seam between the two lists.
+    // record of step j + 2 and the pattern tile of step j + 1 are fetched at the top.  One loop
+    // per sub-tile, so that the accumulators are addressed statically; the prefetch runs across
+    // the seam between the two lists and, harmlessly, one step past the end.
     if (total > 0 && !(a.mode & 1)) {
-      u32x4 ahi;                                  // pattern tile of the current step
+      u32x4 ahi, alo;                             // pattern tile of the current step
       uint32_t base_a, base_b;                    // row addresses of the step whose tiles are being read
       uint32_t off_a, off_b, bt;                  // record of the step after that
       h8 bh[NT], bl[NT];
-      record(0, off_a, off_b, bt);
-      ahi = pattern(bt);
-      base_a = boff + lane_off + off_a;
-      base_b = boff + lane_off + off_b;
+      record(off_a, off_b, bt);
+      pattern(bt, ahi, alo);
+      base_a = stage_lane + off_a;
+      base_b = stage_lane + off_b;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, 0, nt);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, 1, nt);
-      record(min(1, total - 1), off_a, off_b, bt);
-      auto body = [&](auto tt_tag, int j) {
+      record(off_a, off_b, bt);
+      auto body = [&](auto tt_tag) {
         constexpr int TT = decltype(tt_tag)::value;
         // step j + 1: its record is here; pattern tile and row addresses
-        const u32x4 anext = pattern(bt);
-        base_a = boff + lane_off + off_a;
-        base_b = boff + lane_off + off_b;
-        record(min(j + 2, total - 1), off_a, off_b, bt);
+        u32x4 nhi, nlo;
+        pattern(bt, nhi, nlo);
+        base_a = stage_lane + off_a;
+        base_b = stage_lane + off_b;
+        record(off_a, off_b, bt);
         const h8 fhi = __builtin_bit_cast(h8, ahi);
-        const h8 flo = __builtin_bit_cast(h8, ahi & 0x10001000u);   // 1.0 -> 2^-11: the lo plane holds the remainder times 2048
+        const h8 flo = __builtin_bit_cast(h8, alo);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -713,19 +743,37 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
           bl[nt] = read_tile(base_a, base_b, 1, nt);
           __builtin_amdgcn_sched_barrier(0);
         }
-        ahi = anext;
+        ahi = nhi;
+        alo = nlo;
       };
       int j = 0;
-      for (; j < n0; ++j) body(std::integral_constant<int, 0>{}, j);
-      for (; j < total; ++j) body(std::integral_constant<int, 1>{}, j);
+      for (; j < n0; ++j) body(std::integral_constant<int, 0>{});
+      for (; j < total; ++j) body(std::integral_constant<int, 1>{});
     }
+    if (dbg) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+      t_wait += t1 - t0;
+      t_issue += t2 - t1;
+      t_steps += t3 - t2;
+      n_steps += uint32_t(total);
+    }
+  }
+  if (dbg && lane == 0) {
+    atomicAdd(&g_tg_dbg[0], __builtin_amdgcn_s_memtime() - t_begin);
+    atomicAdd(&g_tg_dbg[1], t_wait);
+    atomicAdd(&g_tg_dbg[2], t_issue);
+    atomicAdd(&g_tg_dbg[3], t_steps);
+    atomicAdd(&g_tg_dbg[4], 1ull);
+    atomicAdd(&g_tg_dbg[5], n_steps);
+    atomicAdd(&g_tg_dbg[6], (unsigned long long)ns);
   }
 
   // accumulator register v of a lane: row (v & 3) + 8 (v >> 2) + 4 h of the sub-tile, feature lane & 31 of the N-tile
   const float inv_scale = a.state->inv_scale;
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
-    const int t = tt == 0 ? w : kSubs - 1 - w;
+    const int t = 2 * w + tt;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int rr = kSub * t + (v & 3) + 8 * (v >> 2) + 4 * h;
@@ -788,6 +836,14 @@ void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 1
 }  // namespace sgnn
 
 extern "C" {
+
+// diagnostics: the cycle counters of runs made with tuning key tg_mode bit 16 set; reading clears them
+int sgnn_tilegroup_debug_counters(unsigned long long* out8) {
+  unsigned long long zero[8] = {};
+  HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tg_dbg), sizeof(zero)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tg_dbg), zero, sizeof(zero)));
+  return SGNN_OK;
+}
 
 size_t sgnn_tilegroup_build_workspace_bytes(int64_t n_rows, int64_t nnz) {
   if (n_rows <= 0 || nnz <= 0) return 0;
@@ -898,7 +954,7 @@ int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t sta
   hipLaunchKernelGGL(k_tg_copy_u32, blocks_for(runs + 1 + 128), dim3(T), 0, st, runs + 1, w.step0, p.step0,
                      runs + 1 + 128);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemsetAsync(p.stage_col + stages * kStageCols, 0, kStageCols * 4, st));
+  HIP_TRY(hipMemsetAsync(p.stage_col + stages * kStageCols, 0, 3 * kStageCols * 4, st));
   hipLaunchKernelGGL(k_tg_stage_cols, blocks_for(stages * kStageCols), dim3(T), 0, st, p.G, stages, w.gptr, w.gstage0,
                      w.mcol, p.stage_col);
   HIP_TRY(hipGetLastError());

@@ -50,9 +50,32 @@ t_rg = timeit(lambda: adj.propagate(X, 1))
 err = float((Y_tg - Y_rg).norm() / Y_rg.norm())
 scale = adj.propagate(X.abs(), 1)
 el = float(((Y_tg - Y_rg).abs() / scale.clamp_min(1e-30)).max())
+if os.environ.get("TG_CYCLES"):
+    import ctypes
+    lib = _lib.load()
+    adj.use_tilegroup = True
+    out = (ctypes.c_ulonglong * 8)()
+    fn = lib.sgnn_tilegroup_debug_counters
+    lib.sgnn_tune_set(b"tg_mode", 16)
+    adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
+    adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
+    lib.sgnn_tune_set(b"tg_mode", 0)
+    tot, wait, issue, steps, waves, nsteps, nstages = [out[i] for i in range(7)]
+    print(f"per wavefront: total {tot / waves:.0f} cycles; stage wait {100 * wait / tot:.1f}% issue {100 * issue / tot:.1f}% "
+          f"steps {100 * steps / tot:.1f}%; {steps / nsteps:.0f} cycles per step, {nsteps / nstages:.2f} steps and "
+          f"{wait / nstages:.0f} + {issue / nstages:.0f} + {steps / nstages:.0f} cycles per stage", flush=True)
 if os.environ.get("TG_MODES"):
     adj.use_tilegroup = True
     for m in (1, 2, 3, 0):
         _lib.load().sgnn_tune_set(b"tg_mode", m)
         print(f"mode {m} (1 = no steps, 2 = no row DMA): {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
 print(f"tile-group {t_tg:.3f} ms/hop   row-group {t_rg:.3f} ms/hop   normwise diff {err:.2e}  element-wise {el:.2e}", flush=True)
+if os.environ.get("TG_SWEEP"):
+    adj.use_tilegroup = True
+    lib = _lib.load()
+    for seg in (64, 128, 256):
+        lib.sgnn_tune_set(b"tg_seg", seg)
+        adj._tg = None
+        adj._tg_bufs = {}
+        adj.propagate(X, 1)
+        print(f"tg_seg {seg}: items {adj._tg['items']} partial slots {adj._tg['slots']}: {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
