@@ -8,20 +8,27 @@ config.json:480-503, GNN_tasks.py:76-80).
 
 One step = one call of ``process_data_with_adjacency_high_order`` on a prebuilt
 adjacency handle with X resident in HBM.  Rank 0 prints ONE JSON line.
+
+N = 1 also reports, outside the timed region and under keys of their own: the same
+step on the other benchmark shapes (hub-clipped and weight-2 Reddit, Reddit at F = 128,
+ogbn-products, R-MAT 10 M, PubMed), the CPU restatement of utils.py:81-96 on the SAME
+graph (median of 3 calls, checked against the GPU result), and one SGNN epoch at the
+reference's 10 000 optimiser iterations per layer run.
+
 N > 1 (launched by torch.distributed.run, one rank per GPU) splits the same job
-over the ranks (strong scaling) on a feature_groups x row_ranks grid: a rank owns a
-block of rows of the graph and a slice of the feature columns, and all-gathers the
-scaled row blocks of its slice over RCCL before its SpMM.  Feature slices need no
-exchange at all, row blocks keep the rows wide; which grid is fastest depends on
-the xGMI all-gather rate, so with ``--feature-groups 0`` (default) every grid that
-divides N (and, for grids that exchange, both the plain and the overlapped schedule)
-is timed for a few untimed steps and the fastest is benchmarked.
+over the ranks (strong scaling).  The headline is always the pure row partition:
+every rank owns a block of rows of the graph and all N ranks all-gather the scaled
+row blocks of X over RCCL before their SpMM (plain, or overlapped in feature slices —
+whichever is faster; both are the same partition).  Grids that also split the feature
+columns (feature_groups x row_ranks) are timed for a few steps each and reported as
+``grid_probe_ms`` extras only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,51 +39,168 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, GB/s
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def algorithmic_bytes(n, nnz, F):
     """Bytes one SpMM has to move at least once: CSR (int32 col + fp32 val per
     stored entry, rowptr), both dinv vectors, X read once, Y written once."""
     return nnz * 8 + (n + 1) * 4 + 2 * n * 4 + 2 * n * F * 4
 
 
-def cpu_baseline(n, F, seed, device, sample_edges, repeats=2):
-    """Time the CPU oracle (torch sparse-COO restatement of utils.py:81-96) on a
-    bounded sample: same node count, feature width and R-MAT parameters as the
-    GPU workload, fewer edges so that it finishes in tens of seconds."""
+def kernel_of(adj, F):
+    """(label, kernels of one hop) of the path ``adj.propagate`` takes at width F."""
+    lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
+    if adj._tilegroup_plan(F):
+        return ("tile-group SpMM (512-row groups share fetched rows through LDS; fp16 hi/lo planes of X on "
+                "v_mfma_f32_32x32x16_f16, fp32 accumulation)", "k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine",
+                "k_tg_spmm")
+    R = lib.sgnn_rowgroup_config(F) if adj.use_rowgroup else 0
+    if R:
+        return f"row-group SpMM, R={R}", "k_row_scale + k_rg_spmm + k_rg_combine", "k_rg_spmm"
+    return "plain CSR SpMM", "k_spmm + k_spmm_combine", "k_spmm"
+
+
+def timed_steps(step, steps, warmup, device, world=1, dist=None):
+    """W untimed steps, then K steps between barriers and device syncs.  Returns the wall time of
+    the K steps (max over ranks), the HIP-event time per step on the launch stream, and the
+    average duration of the main SpMM kernel alone (HIP events the library records around it)."""
+    import torch
+    from sgnn_amd import _lib
+    lib = _lib.load()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    lib.sgnn_tune_set(b"time_kernel", 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    k_ms, k_n = _lib.kernel_time_ms()
+    lib.sgnn_tune_set(b"time_kernel", 0)
+    return wall, ev0.elapsed_time(ev1) / steps, (k_ms / k_n if k_n else None), k_n
+
+
+def load_traffic(key):
+    """HBM bytes per launch of the main SpMM kernel from the committed PMC profile, if one matches."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return float(json.load(f)[key]["hbm_fabric_bytes"])
+    except Exception:
+        return None
+
+
+def draw(workload, seed, device, max_degree=None, weight=None):
+    """Graph and operand of one benchmark shape, resident on the device."""
+    import torch
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import SHAPES, rmat_undirected_device
+    n, E, F = SHAPES[workload]
+    t0 = time.perf_counter()
+    row, col = rmat_undirected_device(n, E, seed=seed, device=device, max_degree=max_degree)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    val = None if weight is None else torch.full((row.numel(),), float(weight), device=device)
+    t0 = time.perf_counter()
+    adj = NormAdj.from_coo(row, col, val, n, device)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1)
+    X = torch.randn(n, F, device=device, generator=g)
+    return adj, X, row, col, t_gen, t_build
+
+
+def sub_record(workload, seed, device, max_degree=None, weight=None, min_region_s=0.3):
+    """One benchmark shape beside the headline: ms per step, main kernel, roofline fraction."""
+    import torch
+    adj, X, row, col, t_gen, t_build = draw(workload, seed, device, max_degree, weight)
+    del row, col
+    n, F = X.shape
+    step = lambda: adj.propagate(X, 1)          # noqa: E731
+    for _ in range(2):
+        step()                                   # plans, buffers
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    one = time.perf_counter() - t0
+    steps = max(10, min(2000, int(min_region_s / max(one, 1e-5))))
+    wall, ev_ms, k_ms, _ = timed_steps(step, steps, 2, device)
+    label, kernels, main = kernel_of(adj, F)
+    b_alg = algorithmic_bytes(n, adj.nnz, F)
+    max_deg = int((adj.rowptr[1:] - adj.rowptr[:-1]).max().item())
+    key = workload + ("" if max_degree is None else f"_clip{max_degree}") + ("" if weight is None else f"_w{weight:g}")
+    rec = {"workload": key, "n": n, "nnz": adj.nnz, "F": F, "max_degree": max_deg,
+           "weights": "unit" if weight is None else f"{weight:g} off the diagonal, 1 on it",
+           "steps": steps, "ms_per_step": round(wall * 1e3 / steps, 4), "kernel": label.split(" (")[0],
+           "main_kernel": main, "main_kernel_ms": None if k_ms is None else round(k_ms, 4),
+           "value": adj.nnz * F / (wall / steps), "algorithmic_bytes": b_alg,
+           "frac": b_alg / ((k_ms or ev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "frac_whole_step": b_alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "traffic": load_traffic(key), "adjacency_build_ms": round(t_build * 1e3, 1)}
+    del adj, X
+    torch.cuda.empty_cache()
+    return rec
+
+
+def cpu_baseline(row, col, X_dev, Y_dev, sample_edges, seed, budget_s=150.0):
+    """The CPU restatement of utils.py:81-96 (torch sparse COO ops, as the reference runs them)
+    timed on this host: by default on the SAME graph and operand the GPU steps used, up to three
+    calls (median), stopping early once ``budget_s`` is spent; its result checks the GPU's."""
     import torch
     from oracle import sgnn_oracle as orc
-    from sgnn_amd.graphgen import rmat_undirected_device
-
-    row, col = rmat_undirected_device(n, sample_edges, seed=seed + 100, device=device)
+    n, F = X_dev.shape
+    if sample_edges > 0:
+        from sgnn_amd.graphgen import rmat_undirected_device
+        row, col = rmat_undirected_device(n, sample_edges, seed=seed + 100, device=X_dev.device)
+        Y_dev = None
     idx = torch.stack((row, col)).cpu()
-    nnz = int(idx.shape[1])
-    adj = torch.sparse_coo_tensor(idx, torch.ones(nnz), (n, n))
-    g = torch.Generator().manual_seed(seed)
-    X = torch.randn(n, F, generator=g)
-    best = float("inf")
-    for _ in range(repeats):
+    nnz_a = int(idx.shape[1])
+    adj = torch.sparse_coo_tensor(idx, torch.ones(nnz_a), (n, n))
+    X = X_dev.cpu()
+    times, t_all, Y = [], time.perf_counter(), None
+    for _ in range(3):
         t0 = time.perf_counter()
-        orc.propagate_high_order(adj, X, 1)
-        best = min(best, time.perf_counter() - t0)
-    return {
-        "value": (nnz + n) * F / best,
+        Y = orc.propagate_high_order(adj, X, 1)
+        times.append(time.perf_counter() - t0)
+        log(f"cpu baseline call {len(times)}: {times[-1]:.1f} s")
+        if time.perf_counter() - t_all + times[-1] > budget_s:
+            break
+    med = statistics.median(times)
+    out = {
+        "value": (nnz_a + n) * F / med,
         "unit": "edge·feat/s",
         "cores": int(torch.get_num_threads()),
         "kind": "port",
-        "sample": f"reddit-shape R-MAT n={n} nnz(A)={nnz} F={F} order=1, one call = {best:.2f} s "
-                  f"(best of {repeats}); full op sequence incl. A+I and degree, as the reference redoes them per call",
-        "seconds": best,
+        "sample": (f"the benchmark graph itself: reddit-shape R-MAT n={n}, nnz(A)={nnz_a}, F={F}, order=1"
+                   if sample_edges <= 0 else
+                   f"reddit-shape R-MAT n={n} with nnz(A)={nnz_a} (a sample, not the benchmark graph), F={F}, order=1")
+                  + f"; median of {len(times)} call(s); full op sequence incl. A+I and degree, as the reference "
+                    "redoes them per call",
+        "seconds": med,
+        "seconds_each": [round(t, 2) for t in times],
     }
-
-
-def load_traffic(workload):
-    """HBM bytes per SpMM launch from the committed PMC profile, if one matches."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return float(d[workload]["hbm_fabric_bytes"])
-    except Exception:
-        return None
+    if Y_dev is not None:
+        Yg = Y_dev.cpu()
+        out["gpu_vs_cpu_rel_err"] = float((Yg - Y).norm() / Y.norm())
+        out["gpu_vs_cpu_max_abs_err"] = float((Yg - Y).abs().max())
+    return out
 
 
 def copy_ceiling(device, mib=2048, reps=10):
@@ -100,9 +224,10 @@ def sgnn_epoch(adj, X, device, max_iter, seed):
     """One SGNN "epoch" on the benchmark graph: a backward sweep plus a forward sweep over two
     decoupled layers with a label head (model/SGNN.py:555-559) at the reference's Reddit
     hyper-parameters (config.json:480-503: 128/64 neurons, leaky_relu=0.2, lr 1e-4, batch 512,
-    order 1, eta 1000, 41 classes) except for ``max_iter`` optimiser iterations per layer run
-    instead of 10 000, so that the default bench stays short; the per-iteration time is the
-    reference's own figure of merit (GNN_tasks.py:133-140)."""
+    order 1, eta 1000, 41 classes, 10 000 optimiser iterations per layer run unless
+    ``max_iter`` says otherwise).  Labels are random: there is no dataset offline.  Also times
+    the full-graph projection after every layer run (model/SGNN.py:73-78, 439: ``self(PX)`` over
+    all n rows, plus ``X . U`` once U is trained) to state its share of the epoch."""
     import torch
     from sgnn_amd.stacked import EmbeddingLayer, LayerParam, SupervisedStackedGNN, get_activation
     n, F = X.shape
@@ -120,40 +245,65 @@ def sgnn_epoch(adj, X, device, max_iter, seed):
                        gnn_type=LayerParam.EGCN, learning_rate=1e-4, max_iter=max_iter, lam=1e-6, batch_size=512)
         model.gnns.append(EmbeddingLayer(adj, labels, train, dim, neurons, 41, p, device))
         dim = neurons
+    finish_events = []
+    for layer in model.gnns:
+        def timed(X_in, PX, orig=layer._finish):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(X_in, PX)
+            e1.record()
+            finish_events.append((e0, e1))
+            return out
+        layer._finish = timed
+    (X[:4096] @ model.gnns[0].W).sum().item()          # rocBLAS loads its kernels on first use: not the sweep's cost
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     inputs, _ = model._forward_sweep(False)
     torch.cuda.synchronize()
     t_first = time.perf_counter() - t0
+    first_finish = sum(a.elapsed_time(b) for a, b in finish_events) * 1e-3
+    finish_events.clear()
     t0 = time.perf_counter()
     model._backward_sweep(inputs)
     model._forward_sweep(True)
     torch.cuda.synchronize()
     t_epoch = time.perf_counter() - t0
-    return {"task": "classification, 2 layers (128, 64), batch 512", "max_iter": max_iter,
+    epoch_finish = sum(a.elapsed_time(b) for a, b in finish_events) * 1e-3
+    return {"task": "classification, 2 layers (128, 64), batch 512, random labels", "max_iter": max_iter,
             "first_forward_sweep_s": t_first, "epoch_s": t_epoch, "optimiser_iterations": 4 * max_iter,
             "s_per_iteration": t_epoch / (4 * max_iter),
-            "epoch_s_at_10000_iterations_per_layer_run": t_epoch / max_iter * 10000}
+            "full_graph_projection": {
+                "what": "act(inner(PX . U) . W) over all n rows after every layer run, X . U included once U is trained "
+                        "(stock rocBLAS GEMMs)",
+                "calls_in_epoch": len(finish_events), "seconds_in_epoch": round(epoch_finish, 5),
+                "share_of_epoch": round(epoch_finish / t_epoch, 5),
+                "seconds_in_first_forward_sweep": round(first_finish, 5),
+                "share_of_first_forward_sweep": round(first_finish / t_first, 5)}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="reddit", help="reddit | reddit128 | products | rmat10m | pubmed")
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-degree", type=int, default=None, help="clip hub degree (real Reddit's is ~21.7k)")
+    ap.add_argument("--weight", type=float, default=None,
+                    help="off-diagonal weight (2.0 = the reference's A + A^T Reddit adjacency, data_loader.py:75)")
     ap.add_argument("--slices", type=int, default=2,
                     help="N > 1: feature slices of the exchange/SpMM pipeline (1 = no overlap)")
     ap.add_argument("--feature-groups", type=int, default=0,
-                    help="N > 1: ranks per row block that split the feature columns (0 = time every divisor of N)")
+                    help="N > 1: extra grids to probe beside the row partition: 0 = every divisor of N, 1 = none, "
+                         "k = only k feature groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--epoch-iters", type=int, default=5000,
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the other shapes and the SGNN epoch")
+    ap.add_argument("--epoch-iters", type=int, default=10000,
                     help="N = 1, reddit: optimiser iterations per layer run of the SGNN epoch timed after the "
-                         "SpMM steps (0 = skip; the reference's Reddit config uses 10000)")
-    ap.add_argument("--cpu-sample-edges", type=int, default=10_000_000)
+                         "SpMM steps (0 = skip; 10000 is the reference's Reddit config)")
+    ap.add_argument("--cpu-sample-edges", type=int, default=0,
+                    help="0 = CPU baseline on the benchmark graph itself; > 0 = on an R-MAT sample of that many edges")
     args = ap.parse_args()
 
     import torch
@@ -183,31 +333,32 @@ def main():
 
     n, E, F = SHAPES[args.workload]
     if rank == 0:
-        print(f"[bench] {args.workload}: drawing the graph on {world} rank(s)", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    row, col = rmat_undirected_device(n, E, seed=args.seed, device=device, max_degree=args.max_degree)
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t0
-    g = torch.Generator(device=device)
-    g.manual_seed(args.seed + 1)
-    X = torch.randn(n, F, device=device, generator=g)
-
+        log(f"{args.workload}: drawing the graph on {world} rank(s)")
     extra = {}
+    cpu_inputs = None
     if world == 1:
-        t0 = time.perf_counter()
-        adj = NormAdj.from_coo(row, col, None, n, device)
-        torch.cuda.synchronize()
-        extra["adjacency_build_ms"] = (time.perf_counter() - t0) * 1e3
+        adj, X, row, col, t_gen, t_build = draw(args.workload, args.seed, device, args.max_degree, args.weight)
+        extra["adjacency_build_ms"] = t_build * 1e3
+        if not args.no_cpu_baseline and args.cpu_sample_edges <= 0:
+            cpu_inputs = (row.cpu(), col.cpu())
         del row, col
         nnz = adj.nnz
         step = lambda: adj.propagate(X, args.order)          # noqa: E731
         max_deg = int((adj.rowptr[1:] - adj.rowptr[:-1]).max().item())
+        kernel_path, kernels_in_step, main_kernel = kernel_of(adj, F)
     else:
         from sgnn_amd.dist import PartitionedAdj, grid_layout, make_row_groups
+        t0 = time.perf_counter()
+        row, col = rmat_undirected_device(n, E, seed=args.seed, device=device, max_degree=args.max_degree)
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t0
+        g = torch.Generator(device=device)
+        g.manual_seed(args.seed + 1)
+        X = torch.randn(n, F, device=device, generator=g)
 
         def build_grid(fg):
-            """One candidate grid: a list of (step function, info), one entry per exchange
-            schedule that reproduces the plain one on this machine."""
+            """One grid: a list of (step function, info), one entry per exchange schedule that
+            reproduces the plain one on this machine."""
             row_rank, row_world, fgroup, f0, f1 = grid_layout(rank, world, fg, F)
             group = make_row_groups(world, fg)
             t0 = time.perf_counter()
@@ -237,7 +388,10 @@ def main():
             for sl in schedules:
                 info = {"feature_groups": fg, "row_ranks": row_world, "features_per_rank": f1 - f0,
                         "exchange_slices": sl, "adjacency_build_ms": build_ms, "nnz": padj.global_nnz,
-                        "max_deg": padj.global_max_degree}
+                        "max_deg": padj.global_max_degree,
+                        "exchange_ranks": dist.get_world_size(group) if row_world > 1 else 1,
+                        "exchange_bytes_per_rank_per_hop": padj.max_rows * row_world * ((f1 - f0 + 3) // 4 * 4) * 4
+                                                           if row_world > 1 else 0}
                 out.append(((lambda sl=sl: padj.propagate(Xl, args.order, slices=sl)), info))
             return out
 
@@ -254,80 +408,93 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
-        if args.feature_groups > 0:
-            candidates = [args.feature_groups]
-        else:
-            candidates = [g for g in range(1, world + 1) if world % g == 0 and g <= F]
-        best = None
-        probed = {}
-        n_options = 0
-        for fg in candidates:
+        def probe_grid(fg, probed):
+            best = None
             for step_fn, info in build_grid(fg):
-                n_options += 1
                 t = probe(step_fn)
                 tag = f"{fg}x{world // fg}" + (f"/s{info['exchange_slices']}" if info["exchange_slices"] > 1 else "")
                 probed[tag] = round(t * 1e3, 3)
                 if rank == 0:
-                    print(f"[bench] {fg} feature slices x {world // fg} row blocks, exchange in "
-                          f"{info['exchange_slices']} slice(s): built in {info['adjacency_build_ms']:.0f} ms, "
-                          f"probe {t * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
+                    log(f"{fg} feature slices x {world // fg} row blocks, exchange in {info['exchange_slices']} "
+                        f"slice(s): built in {info['adjacency_build_ms']:.0f} ms, probe {t * 1e3:.2f} ms/step")
                 if best is None or t < best[0]:
                     best = (t, step_fn, info)
-                del step_fn
+            return best
+
+        probed = {}
+        # the headline: the pure row partition, all `world` ranks in one all-gather
+        _, step, info = probe_grid(1, probed)
+        if args.feature_groups == 0:
+            others = [g for g in range(2, world + 1) if world % g == 0 and g <= F]
+        else:
+            others = [args.feature_groups] if args.feature_groups > 1 else []
+        for fg in others:                            # extras: reported, never benchmarked
+            probe_grid(fg, probed)
             torch.cuda.empty_cache()
-        _, step, info = best
         del row, col, X
         nnz, max_deg = info.pop("nnz"), info.pop("max_deg")
         extra.update(info)
-        if n_options > 1:
+        extra["collective"] = (f"all_gather_into_tensor among {info['exchange_ranks']} ranks, backend "
+                               f"{dist.get_backend()} ({'gloo rehearsal on one GPU' if rehearsal else 'RCCL'}), "
+                               f"world size {dist.get_world_size()}")
+        if rank == 0:
+            log(f"headline: row partition over {info['exchange_ranks']} ranks; {extra['collective']}")
+        if len(probed) > 1:
             extra["grid_probe_ms"] = probed
+        lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
+        R = lib.sgnn_rowgroup_config(F)
+        kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
+        kernels_in_step = "k_row_scale + all-gather + " + ("k_rg_spmm + k_rg_combine" if R else "k_spmm")
+        main_kernel = "k_rg_spmm" if R else "k_spmm"
 
-    lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
-    R = lib.sgnn_rowgroup_config(extra.get("features_per_rank", F))
-    kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
-    tilegroup = world == 1 and bool(getattr(adj, "_tilegroup_plan", lambda F: None)(F))
-    if tilegroup:
-        kernel_path = "tile-group SpMM (512-row groups, fp16 hi/lo planes on v_mfma_f32_32x32x16_f16, fp32 accumulation)"
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    ev_ms = ev0.elapsed_time(ev1) / args.steps              # HIP events on the launch stream
+    wall, ev_ms, k_ms, k_n = timed_steps(step, args.steps, args.warmup, device, world, dist if world > 1 else None)
 
     copy_gbps = None
+    epoch = None
+    others = []
+    cpu = None
     if rank == 0 and world == 1:
         try:
             copy_gbps = copy_ceiling(device)
         except Exception as exc:
-            print(f"[bench] copy ceiling not measured: {exc}", file=sys.stderr, flush=True)
-    epoch = None
-    if world == 1 and args.workload == "reddit" and args.epoch_iters > 0:   # outside the timed SpMM region
-        try:
-            epoch = sgnn_epoch(adj, X, device, args.epoch_iters, args.seed)
-        except Exception as exc:                  # the SpMM line must come out whatever happens here
-            epoch = {"error": f"{type(exc).__name__}: {exc}"}
+            log(f"copy ceiling not measured: {exc}")
+        if not args.no_cpu_baseline:
+            try:
+                Y = adj.propagate(X, 1)
+                if cpu_inputs is not None:
+                    cpu = cpu_baseline(cpu_inputs[0], cpu_inputs[1], X, Y, 0, args.seed)
+                else:
+                    cpu = cpu_baseline(None, None, X, None, args.cpu_sample_edges, args.seed)
+                del Y
+            except Exception as exc:
+                cpu = {"error": f"{type(exc).__name__}: {exc}"}
+            cpu_inputs = None
+        if args.workload == "reddit" and args.epoch_iters > 0 and not args.no_extras:   # outside the timed SpMM region
+            log(f"SGNN epoch at {args.epoch_iters} iterations per layer run")
+            try:
+                epoch = sgnn_epoch(adj, X, device, args.epoch_iters, args.seed)
+            except Exception as exc:                  # the SpMM line must come out whatever happens here
+                epoch = {"error": f"{type(exc).__name__}: {exc}"}
+        if args.workload == "reddit" and args.max_degree is None and args.weight is None and not args.no_extras:
+            del adj, X
+            torch.cuda.empty_cache()
+            for wl, md, wt in (("reddit", 22000, None), ("reddit", None, 2.0), ("reddit", 22000, 2.0),
+                               ("reddit128", None, None), ("products", None, None), ("rmat10m", None, None),
+                               ("pubmed", None, None)):
+                log(f"other shapes: {wl} max_degree={md} weight={wt}")
+                try:
+                    others.append(sub_record(wl, args.seed, device, md, wt))
+                except Exception as exc:
+                    others.append({"workload": wl, "error": f"{type(exc).__name__}: {exc}"})
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         units = nnz * F * args.order                          # (E + n) . F per hop
-        b_alg = algorithmic_bytes(n, nnz, F) * args.order
-        achieved = b_alg / (ev_ms * 1e-3) / 1e9
+        b_alg = algorithmic_bytes(n, nnz, F)                   # per launch of the main kernel (one hop)
+        launches_per_step = (k_n / args.steps) if k_n else args.order
+        kernel_ms = k_ms if k_ms else ev_ms / launches_per_step
+        achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+        key = args.workload + ("" if args.max_degree is None else f"_clip{args.max_degree}") \
+            + ("" if args.weight is None else f"_w{args.weight:g}")
         out = {
             "metric": "Â·X SpMM edge·feat/s (Reddit F=602)" if args.workload == "reddit"
                       else f"Â·X SpMM edge·feat/s ({args.workload})",
@@ -344,29 +511,34 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}-shape symmetric R-MAT(0.57,0.19,0.19,0.05): n={n}, "
-                            f"nnz(A+I)={nnz}, F={F}, order={args.order}, max_degree={max_deg}, unit weights",
+                            f"nnz(A+I)={nnz}, F={F}, order={args.order}, max_degree={max_deg}, "
+                            + ("unit weights" if args.weight is None else f"weight {args.weight:g} off the diagonal"),
                 "rows": "one GPU" if world == 1 else
-                        f"{extra['feature_groups']} feature slices x {extra['row_ranks']} row blocks over {world} GPUs, "
-                        "all-gather of scaled X blocks inside a feature slice",
+                        f"row partition: {extra['row_ranks']} row blocks over {world} GPUs, all-gather of the scaled "
+                        "X blocks",
+                "arithmetic": "fp32 in, fp32 out, fp32 accumulation; the tile-group kernel feeds the matrix cores X as "
+                              "two fp16 planes (hi + lo/2048 at a power-of-two scale) that reproduce each fp32 input to "
+                              "2^-22 relative; operands they cannot represent take the plain fp32 kernel"
+                              if main_kernel == "k_tg_spmm" else "fp32 throughout",
                 "graph_gen_s": round(t_gen, 2),
                 "kernel": kernel_path,
                 **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in extra.items()},
             },
             "roofline": {
                 "bound": "hbm",
+                "kernel": main_kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": load_traffic(args.workload) if world == 1 else None,
+                "traffic": load_traffic(key) if world == 1 else None,
                 "algorithmic_bytes": b_alg,
-                "kernel_ms": ev_ms,                           # HIP events around the K steps / K
-                "kernels_in_step": "k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine" if tilegroup else
-                                   ("k_row_scale + k_rg_spmm + k_rg_combine"
-                                    + (" (rocprof, profiles/r01_reddit_f602_rowgroup_x4.json: 0.19 + 9.65 + 0.58 ms)"
-                                       if args.workload == "reddit" and world == 1 else "")) if R
-                                   else "k_spmm (+ k_row_scale)",
-                "gather_bytes_no_reuse": nnz * F * 4 * args.order,
+                "kernel_ms": kernel_ms,                       # HIP events around every launch of the main kernel
+                "kernel_launches_timed": k_n,
+                "step_ms": ev_ms,                             # HIP events around the K steps / K: all kernels of a step
+                "frac_whole_step": b_alg * args.order / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "kernels_in_step": kernels_in_step,
+                "gather_bytes_no_reuse": nnz * F * 4,
             },
         }
         roof = out["roofline"]
@@ -374,14 +546,13 @@ def main():
             roof["copy_ceiling"] = copy_gbps
             roof["frac_of_copy"] = achieved / copy_gbps
         if roof["traffic"]:                                   # bytes the L2s fetched or wrote, per launch
-            roof["fabric_GBps"] = roof["traffic"] / (ev_ms * 1e-3) / 1e9
+            roof["fabric_GBps"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9
         if epoch:
             out["sgnn_epoch"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in epoch.items()}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(n, F, args.seed, device, args.cpu_sample_edges)
-            except Exception as exc:
-                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if others:
+            out["other_workloads"] = others
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -58,9 +58,20 @@ int sgnn_version(void);
  * safe).  Keys: "tile" = feature-slice width in floats owned by one wavefront,
  * "unroll" = row fetches issued back to back (2 or 4), "rg_seg" = merged columns per
  * row-group work item, "rg_R" = rows per group, 8 or 16, "rg_order" = width of the column blocks the work
- * items are ordered by (all three affect plans built afterwards); value 0 restores the
- * built-in policy.  No reference counterpart. */
+ * items are ordered by (all three affect plans built afterwards), "tg_seg" = stages per
+ * tile-group work item, "tg_mode" = diagnostic switches of the tile-group kernel,
+ * "time_kernel" = 1/0 turns the kernel timer on/off (see sgnn_kernel_time_ms); value 0
+ * restores the built-in policy.  No reference counterpart. */
 int sgnn_tune_set(const char* key, int value);
+
+/* With sgnn_tune_set("time_kernel", 1) every SpMM entry point brackets its main kernel
+ * (k_tg_spmm, k_rg_spmm or k_spmm; not the scaling, split or combine kernels around it)
+ * with a pair of HIP events on the launch stream.  This call waits for the recorded
+ * launches, returns the sum of their durations in milliseconds and their number, and
+ * starts a new count (at most 8192 launches are kept between two reads).  The
+ * reference's counterpart is the wall-clock print at GNN_tasks.py:133-140; this is the
+ * per-kernel figure a roofline needs.  Not thread safe. */
+int sgnn_kernel_time_ms(double* total_ms, int64_t* launches);
 
 /* Message of the calling thread's most recent failure ("" if none).
  * The reference raises Python exceptions; the host layer turns a negative
@@ -200,8 +211,12 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           nullable; utils.py:93 when it is dinv); `state` is 16 bytes of
  *                           device memory that carries the scale and the fall-back flag to
  *                           the SpMM call that follows on the same stream
- *   sgnn_spmm_tilegroup_f32   Y = diag(dinv_row) . (w_off * pattern) . planes, epilogue as
- *                           sgnn_spmm_csr_f32.  rowptr / colidx / vals / dinv_col / X / ldx /
+ *   sgnn_spmm_tilegroup_f32   Y = diag(dinv_row) . (w_off * pattern + diag(corr)) . planes,
+ *                           epilogue as sgnn_spmm_csr_f32.  corr (nullable, square matrices
+ *                           only) = stored diagonal value - w_off per row: the loaders'
+ *                           A + A^T carries 2.0 off the diagonal (data_loader.py:75) and
+ *                           utils.py:83-86 puts 1.0 on it; its term is taken from X in fp32.
+ *                           rowptr / colidx / vals / dinv_col / X / ldx /
  *                           csr_workspace describe the same product for the fall-back
  *                           (X and dinv_col as given to the split call, csr_workspace of
  *                           sgnn_spmm_workspace_bytes); rowptr == NULL: no fall-back is
@@ -224,8 +239,8 @@ int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, 
 size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F);
 int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
                             int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
-                            const float* dinv_row, float w_off, const void* planes, size_t planes_bytes,
-                            const void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                            const float* dinv_row, float w_off, const float* corr, const void* planes,
+                            size_t planes_bytes, const void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
                             size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                             const float* vals, const float* dinv_col, const float* X, int64_t ldx,
                             void* csr_workspace, size_t csr_workspace_bytes, void* stream);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "sgnn_version": (c_int, []),
     "sgnn_tune_set": (c_int, [c_char_p, c_int]),
     "sgnn_last_error": (c_char_p, []),
+    "sgnn_kernel_time_ms": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
     "sgnn_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgnn_build_norm_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -68,7 +69,7 @@ SIGNATURES = {
                                          c_void_p]),
     "sgnn_spmm_tilegroup_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgnn_spmm_tilegroup_f32": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_size_t, c_int64, c_int64, c_int64,
-                                        c_int64, c_int64, c_void_p, c_float, c_void_p, c_size_t, c_void_p, c_void_p,
+                                        c_int64, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                         c_int64, c_int, c_void_p, c_size_t, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
@@ -131,6 +132,14 @@ def check(rc):
     if rc != 0:
         msg = load().sgnn_last_error().decode("utf-8", "replace")
         raise SgnnHipError(f"libsgnn_hip error {rc}: {msg}")
+
+
+def kernel_time_ms():
+    """(sum of the main SpMM kernels' durations in ms, launches) since the last read; needs
+    ``sgnn_tune_set(b"time_kernel", 1)``."""
+    total, launches = ctypes.c_double(0), c_int64(0)
+    check(load().sgnn_kernel_time_ms(ctypes.byref(total), ctypes.byref(launches)))
+    return total.value, launches.value
 
 
 def ptr(t):

@@ -40,6 +40,13 @@ int spmm_csr_guarded(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t F, con
                      const float* X, int64_t ldx, float* Y, int64_t ldy, int epilogue, void* workspace,
                      size_t workspace_bytes, const uint32_t* guard, hipStream_t stream);
 
+// Kernel timer (sgnn_tune_set("time_kernel", 1)): while it is on, every SpMM entry point
+// brackets its main kernel (k_tg_spmm / k_rg_spmm / k_spmm; not the scale, split or combine
+// kernels around it) with a pair of HIP events on the launch stream; sgnn_kernel_time_ms
+// adds them up.  Off, both calls return at once and create nothing.
+void kernel_timer_begin(hipStream_t stream);
+void kernel_timer_end(hipStream_t stream);
+
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \

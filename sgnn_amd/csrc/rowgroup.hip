@@ -691,6 +691,7 @@ int launch_rg(const RgArgs& a, hipStream_t st) {
   constexpr int UW = U * R <= kWave ? U : kWave / R;   // with weights: a step's U*R weights in one load
   const dim3 grid(unsigned((a.items + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWave * kWavesPerBlock);
   const bool bigx = a.x_bytes >= kBigX;
+  sgnn::kernel_timer_begin(st);
   if (a.gw != nullptr) {
     if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, true, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, false, true>), grid, block, 0, st, a);
@@ -699,6 +700,7 @@ int launch_rg(const RgArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, false, false>), grid, block, 0, st, a);
   }
   HIP_TRY(hipGetLastError());
+  sgnn::kernel_timer_end(st);
   if (a.n_long > 0) {
     hipLaunchKernelGGL(k_rg_combine<R>, dim3(unsigned(a.n_long), R), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <vector>
 
 namespace {
 using namespace sgnn;
@@ -370,9 +371,11 @@ int launch_spmm(const SpmmArgs& a, hipStream_t st) {
   const unsigned ftiles = unsigned((a.F + tile - 1) / tile);
   const unsigned row_blocks = unsigned((int64_t(a.n_rows) + kWavesPerBlock - 1) / kWavesPerBlock);
   const unsigned seg_blocks = unsigned((int64_t(a.max_segs) + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (!a.guard) sgnn::kernel_timer_begin(st);
   hipLaunchKernelGGL((k_spmm<V, LPR, C, U>), dim3(row_blocks + seg_blocks, ftiles), dim3(kWave * kWavesPerBlock), 0,
                      st, a, row_blocks);
   HIP_TRY(hipGetLastError());
+  if (!a.guard) sgnn::kernel_timer_end(st);
   const unsigned fy = unsigned((a.F + 255) / 256 > 8 ? 8 : (a.F + 255) / 256);
   hipLaunchKernelGGL(k_spmm_combine, dim3(unsigned(a.max_long), fy), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -487,6 +490,32 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+
+namespace {
+struct TimerPair { hipEvent_t e0, e1; };
+constexpr size_t kMaxTimed = 8192;      // launches kept between two reads; later ones go untimed
+bool g_timer_on = false;
+std::vector<TimerPair> g_timer_pool;    // events are created on first use and kept
+size_t g_timer_used = 0;
+bool g_timer_open = false;
+}  // namespace
+
+void kernel_timer_begin(hipStream_t st) {
+  if (!g_timer_on || g_timer_open || g_timer_used >= kMaxTimed) return;
+  if (g_timer_used == g_timer_pool.size()) {
+    TimerPair p;
+    if (hipEventCreate(&p.e0) != hipSuccess) return;
+    if (hipEventCreate(&p.e1) != hipSuccess) { (void)hipEventDestroy(p.e0); return; }
+    g_timer_pool.push_back(p);
+  }
+  if (hipEventRecord(g_timer_pool[g_timer_used].e0, st) == hipSuccess) g_timer_open = true;
+}
+
+void kernel_timer_end(hipStream_t st) {
+  if (!g_timer_open) return;
+  g_timer_open = false;
+  if (hipEventRecord(g_timer_pool[g_timer_used].e1, st) == hipSuccess) ++g_timer_used;
+}
 }  // namespace sgnn
 
 extern "C" {
@@ -502,11 +531,27 @@ int sgnn_tune_set(const char* key, int value) {
   else if (!std::strcmp(key, "rg_order")) sgnn::set_rowgroup_order(value);
   else if (!std::strcmp(key, "tg_seg")) sgnn::set_tilegroup_segment(value);
   else if (!std::strcmp(key, "tg_mode")) sgnn::set_tilegroup_mode(value);
+  else if (!std::strcmp(key, "time_kernel")) { sgnn::g_timer_on = value != 0; sgnn::g_timer_used = 0; }
   else return fail(SGNN_ERR_INVALID, std::string("unknown tuning key ") + key);
   return SGNN_OK;
 }
 
 const char* sgnn_last_error(void) { return sgnn::g_err.c_str(); }
+
+int sgnn_kernel_time_ms(double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches) return fail(SGNN_ERR_INVALID, "null pointer");
+  double sum = 0;
+  for (size_t i = 0; i < sgnn::g_timer_used; ++i) {
+    float ms = 0;
+    HIP_TRY(hipEventSynchronize(sgnn::g_timer_pool[i].e1));
+    HIP_TRY(hipEventElapsedTime(&ms, sgnn::g_timer_pool[i].e0, sgnn::g_timer_pool[i].e1));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = int64_t(sgnn::g_timer_used);
+  sgnn::g_timer_used = 0;
+  return SGNN_OK;
+}
 
 size_t sgnn_spmm_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t F) {
   (void)n_rows;

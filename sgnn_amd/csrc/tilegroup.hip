@@ -509,8 +509,12 @@ struct TgArgs {
   const char* planes;
   const TgState* state;
   const float* dinv_row;
+  // diagonal of its own (A + A^T has weight 2 off the diagonal, A + I puts 1 on it): the
+  // weighted row sum is w_off * (pattern sum) + corr[i] * x'_i with x' the operand as the
+  // planes hold it, i.e. X (times dinv_col per row when that is given); NULL = none
+  const float *corr, *X, *dinv_col;
   float *Y, *partial;
-  int64_t ldy, slice_bytes;   // slice_bytes = n_cols * 512
+  int64_t ldy, ldx, slice_bytes;   // slice_bytes = n_cols * 512
   int32_t items, n_long, F, Fpad, epilogue;
   float w_off;
   int32_t mode;
@@ -779,15 +783,17 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
       const int rr = kSub * t + (v & 3) + 8 * (v >> 2) + 4 * h;
       const int row = a.grows[int64_t(g) * kRows + rr];
       if (row < 0) continue;
-      float dr = 1.0f;
+      float dr = 1.0f, cr = 0.0f;
       if (out < 0 && a.dinv_row != nullptr) dr = a.dinv_row[row];
+      if (out < 0 && a.corr != nullptr) cr = a.corr[row] * (a.dinv_col != nullptr ? a.dinv_col[row] : 1.0f);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int f = slice * kSlice + nt * 32 + (lane & 31);
         float y = acc[tt][nt][v] * inv_scale;   // exact: a power of two
         if (out < 0) {
           if (f >= a.F) continue;
-          if (a.w_off != 1.0f) y *= a.w_off;
+          if (a.corr != nullptr) y = fmaf(a.w_off, y, cr * a.X[int64_t(row) * a.ldx + f]);
+          else if (a.w_off != 1.0f) y *= a.w_off;
           if (a.dinv_row != nullptr) {
             y = y * dr;
             if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
@@ -811,12 +817,14 @@ __global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
     if (row < 0) continue;
     const bool scale = a.dinv_row != nullptr;
     const float dr = scale ? a.dinv_row[row] : 1.0f;
+    const float cr = a.corr != nullptr ? a.corr[row] * (a.dinv_col != nullptr ? a.dinv_col[row] : 1.0f) : 0.0f;
     for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
       const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f;
       const int64_t stride = int64_t(kRows) * a.Fpad;
       float s = 0.0f;
       for (int k = 0; k < nseg; ++k) s += pp[k * stride];
-      if (a.w_off != 1.0f) s *= a.w_off;
+      if (a.corr != nullptr) s = fmaf(a.w_off, s, cr * a.X[int64_t(row) * a.ldx + f]);
+      else if (a.w_off != 1.0f) s *= a.w_off;
       if (scale) {
         s = s * dr;
         if (a.epilogue == SGNN_EPI_SCALE_ROW2) s = s * dr;
@@ -1014,7 +1022,8 @@ size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F) {
 
 int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
                             int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
-                            const float* dinv_row, float w_off, const void* planes, size_t planes_bytes,
+                            const float* dinv_row, float w_off, const float* corr, const void* planes,
+                            size_t planes_bytes,
                             const void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
                             size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                             const float* vals, const float* dinv_col, const float* X, int64_t ldx,
@@ -1024,6 +1033,8 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   if (ldy < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
   if (epilogue != SGNN_EPI_SCALE_ROW && epilogue != SGNN_EPI_SCALE_ROW2)
     return fail(SGNN_ERR_INVALID, "unknown epilogue mode");
+  if (corr != nullptr && (!X || ldx < F || n_rows != n_cols))
+    return fail(SGNN_ERR_INVALID, "a diagonal correction needs X and a square matrix");
   if (stages <= 0 || steps <= 0 || items <= 0 || partial_slots < 0 || long_groups < 0)
     return fail(SGNN_ERR_INVALID, "counts do not match the plan");
   TgPlan p = carve_tg_plan(const_cast<void*>(plan), n_rows, stages, steps, items, long_groups);
@@ -1041,6 +1052,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   a.planes = static_cast<const char*>(planes);
   a.state = static_cast<const TgState*>(state);
   a.dinv_row = dinv_row; a.Y = Y; a.partial = static_cast<float*>(workspace);
+  a.corr = corr; a.X = X; a.dinv_col = dinv_col; a.ldx = ldx;
   a.ldy = ldy; a.slice_bytes = n_cols * kRowBytes;
   a.items = int32_t(items); a.n_long = int32_t(long_groups);
   a.F = int32_t(F); a.Fpad = int32_t(slices * kSlice); a.epilogue = epilogue; a.w_off = w_off;
@@ -1052,8 +1064,10 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     attr_set = true;
   }
+  sgnn::kernel_timer_begin(st);
   hipLaunchKernelGGL((k_tg_spmm<4>), dim3(unsigned(items), unsigned(slices)), dim3(kWaves * kWave), kLdsBytes, st, a);
   HIP_TRY(hipGetLastError());
+  sgnn::kernel_timer_end(st);
   if (long_groups > 0) {
     hipLaunchKernelGGL(k_tg_combine, dim3(unsigned(long_groups), 64), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -248,11 +248,11 @@ class NormAdj:
     TILEGROUP_MIN_SHARING = 4.0
 
     def _tilegroup_plan(self, F):
-        """Tile-group plan, or None when that kernel does not apply (weights that differ,
-        a diagonal of its own, narrow features, rows that share too few columns, switched off)."""
+        """Tile-group plan, or None when that kernel does not apply (off-diagonal weights that
+        differ, narrow features, rows that share too few columns, switched off)."""
         if self.use_tilegroup is False or not self.use_rowgroup or self.nnz == 0:
             return None
-        if self.w_off is None or self.corr is not None:
+        if self.w_off is None:
             return None
         auto = self.use_tilegroup is None
         if auto and (F < 96 or self.n < 8192 or self.nnz < 32 * self.n):
@@ -299,7 +299,7 @@ class NormAdj:
                                                 _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), st))
         _lib.check(lib.sgnn_spmm_tilegroup_f32(
             self.n, self.n, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"],
-            plan["slots"], plan["n_long"], dinv if scale_rows else None, float(self.w_off),
+            plan["slots"], plan["n_long"], dinv if scale_rows else None, float(self.w_off), _lib.ptr(self.corr),
             _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), _lib.ptr(Y), ldy, int(epilogue),
             _lib.ptr(bufs["ws"]), bufs["ws"].numel(), self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
             _lib.ptr(self._vals), dinv if scale_cols else None, _lib.ptr(X), ldx, _lib.ptr(csr_ws), csr_ws.numel(), st))

@@ -41,8 +41,14 @@ def test_tilegroup_matches_oracle(gpu_device, n, edges, F, order):
 
 def test_tilegroup_weight2_and_single_hop_entry(gpu_device):
     adj, r, c, v = _graph(2500, 60_000, seed=5, dev=gpu_device, weight=2.0)
-    assert adj.w_off == 2.0 and adj.corr is not None      # diagonal 1.0 differs from the weight: other kernels
-    assert adj._tilegroup_plan(128) is None
+    assert adj.w_off == 2.0 and adj.corr is not None      # A + A^T then A + I: 2.0 off the diagonal, 1.0 on it
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, 2500)
+    Xn = np.random.default_rng(3).standard_normal((2500, 130)).astype(np.float32)
+    exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, Xn))
+    Yc = adj.propagate(torch.from_numpy(Xn).to(gpu_device), 2).cpu().numpy()
+    assert adj._tg and int(adj._tg_bufs[130]["state"][1].item()) == 0
+    assert rel_err(Yc, exp) <= TOL
+    assert scaled_err(Yc, exp, abs_scale(rowptr, colidx, vals, dinv, dinv, Xn, 2)) <= TOL
     from sgnn_amd import NormAdj
     adj2 = NormAdj.from_coo(r, c, v, 2500, gpu_device, self_loops=0, zero_inf=True)
     adj2.use_tilegroup = True
@@ -98,7 +104,8 @@ def test_tilegroup_wide_range_and_nonfinite_fall_back(gpu_device):
     assert float(((Y - Y_ref).abs() / scale).max()) <= TOL
 
 
-def test_tilegroup_hub_graph_with_split_groups(gpu_device):
+@pytest.mark.parametrize("weight", [None, 2.0])
+def test_tilegroup_hub_graph_with_split_groups(gpu_device, weight):
     """A graph whose top group's merged list is cut into several work items (partial rows + combine)."""
     from sgnn_amd import NormAdj, _lib
     from sgnn_amd.graphgen import rmat_undirected_device
@@ -108,7 +115,9 @@ def test_tilegroup_hub_graph_with_split_groups(gpu_device):
     try:
         n, F = 60_000, 200
         row, col = rmat_undirected_device(n, 6_000_000, seed=2, device=dev)
-        adj = NormAdj.from_coo(row, col, None, n, dev)
+        val = None if weight is None else torch.full((row.numel(),), weight, device=dev)
+        adj = NormAdj.from_coo(row, col, val, n, dev)
+        assert (adj.corr is not None) == (weight is not None)
         adj.use_tilegroup = True
         X = torch.randn(n, F, device=dev)
         Y = adj.propagate(X, 1)

@@ -19,7 +19,7 @@ def one(pattern):
 
 def main():
     root = sys.argv[1]
-    needle = sys.argv[2] if len(sys.argv) > 2 else "k_spmm<"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "k_tg_spmm"
     out = {"dir": root, "kernel_filter": needle}
     stats = one(os.path.join(root, "trace", "**", "*_kernel_stats.csv"))
     if stats:
@@ -45,6 +45,9 @@ def main():
         out["fetch_bytes_raw"] = pmc["FETCH_SIZE"] * 1024
     if "WRITE_SIZE" in pmc:
         out["write_bytes"] = pmc["WRITE_SIZE"] * 1024
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # gfx950: FETCH_SIZE counts 64-byte requests as 32 bytes, hence the factor 2
+        out["hbm_fabric_bytes"] = 2 * out["fetch_bytes_raw"] + out["write_bytes"]
     if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
         out["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
     print(json.dumps(out, indent=1))
