@@ -92,7 +92,7 @@ struct TgPlan {
   int32_t* stage_col;     // [stages * 64] columns of a stage (tail of a group's last stage: its first column again)
   int32_t* step0;         // [stages * 16 + 1 (+ slack)] first step of (stage, sub-tile)
   uint16_t* step_slots;   // [(steps + slack) * 16] per column of a step: byte offset of its row in the stage's LDS image
-                          // (slot * 512, plus (slot & 3) * 64: the swizzle of the row's 64-byte segments)
+                          // ((slot >> 2) * 2048 + (slot & 3) * 64: blocks of 4 rows, stored segment-major)
   uint16_t* step_bits;    // [(steps + slack) * 32] per row of the sub-tile: which of the 16 columns it has
   int32_t *item_group, *item_s0, *item_s1, *item_out;   // [items] in launch order
   int32_t *long_group, *long_slot, *long_nseg;          // [long groups]
@@ -131,7 +131,7 @@ struct TgBuild {
   int32_t* mcol;            // [nnz] merged columns, all groups back to back
   int32_t* gptr;            // [G + 1] merged-list offsets
   uint32_t *gns, *gstage0;  // [G], [G + 1] stages per group and their running sum
-  uint32_t *runcount, *runfirst, *nsteps, *step0;   // [cap_runs (+1)]
+  uint32_t *runcount, *runclass, *runfirst, *nsteps, *step0;   // [cap_runs (+1)]
   uint32_t *nseg, *first, *lseg, *slot0, *lflag, *lidx;   // [G]
   uint64_t *ikey_a, *ikey_b;   // [cap_items]
   int32_t* itmp;               // [4 * cap_items]
@@ -163,6 +163,7 @@ TgBuild carve_tg_build(void* base, int64_t n_rows, int64_t nnz) {
   w.gns = c.take<uint32_t>(w.G + 1);
   w.gstage0 = c.take<uint32_t>(w.G + 1);
   w.runcount = c.take<uint32_t>(w.cap_runs + 1);
+  w.runclass = c.take<uint32_t>(w.cap_runs + 1);
   w.runfirst = c.take<uint32_t>(w.cap_runs + 1);
   w.nsteps = c.take<uint32_t>(w.cap_runs + 1);
   w.step0 = c.take<uint32_t>(w.cap_runs + 1);
@@ -263,17 +264,22 @@ __global__ void k_tg_step_keys(int64_t nnz, const uint64_t* __restrict__ keys1, 
   // pos[] is the exclusive scan of the heads: an entry that is not a head sits in merged column pos[i] - 1
   const uint32_t m = (head[i] ? pos[i] : pos[i] - 1u) - uint32_t(gptr[g]);
   const uint64_t stage = uint64_t(gstage0[g]) + m / kStageCols;
-  keys2[i] = ((stage * kSubs + (r9 >> 5)) << (5 + kSlotBits)) | (uint64_t(m % kStageCols) << 5) | uint64_t(r9 & 31);
+  // inside a run the columns are ordered by bank class (slot & 3) first: k_tg_fill_steps deals
+  // them out round-robin over the classes from that order
+  const uint32_t slot = m % kStageCols;
+  const uint32_t cls_major = ((slot & 3u) << (kSlotBits - 2)) | (slot >> 2);
+  keys2[i] = ((stage * kSubs + (r9 >> 5)) << (5 + kSlotBits)) | (uint64_t(cls_major) << 5) | uint64_t(r9 & 31);
 }
 
 // columns of every (stage, sub-tile) run, and where the run's first (sub-tile, column) pair sits
 __global__ void k_tg_run_counts(int64_t nnz, const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ head,
                                 const uint32_t* __restrict__ pair, uint32_t* __restrict__ runcount,
-                                uint32_t* __restrict__ runfirst) {
+                                uint32_t* __restrict__ runclass, uint32_t* __restrict__ runfirst) {
   int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (i >= nnz || !head[i]) return;
   const uint64_t run = keys2[i] >> (5 + kSlotBits);
   atomicAdd(&runcount[run], 1u);
+  atomicAdd(&runclass[run], 1u << (8 * ((uint32_t(keys2[i]) >> (5 + kSlotBits - 2)) & 3u)));   // four counts of at most 32
   if (i == 0 || (keys2[i - 1] >> (5 + kSlotBits)) != run) runfirst[run] = pair[i];
 }
 
@@ -348,19 +354,34 @@ __global__ void k_tg_stage_cols(int64_t G, int64_t stages, const int32_t* __rest
 
 __global__ void k_tg_fill_steps(int64_t nnz, const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ head,
                                 const uint32_t* __restrict__ pair, const uint32_t* __restrict__ runfirst,
+                                const uint32_t* __restrict__ runclass,
                                 const uint32_t* __restrict__ step0, uint16_t* __restrict__ step_slots,
                                 uint32_t* __restrict__ step_bits32) {
   int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (i >= nnz) return;
   const uint64_t k = keys2[i];
   const uint64_t run = k >> (5 + kSlotBits);
-  const uint32_t slot = uint32_t(k >> 5) & uint32_t(kStageCols - 1), r5 = uint32_t(k) & 31u;
+  const uint32_t cm = uint32_t(k >> 5) & uint32_t(kStageCols - 1), r5 = uint32_t(k) & 31u;
+  const uint32_t cls = cm >> (kSlotBits - 2), slot = ((cm & ((1u << (kSlotBits - 2)) - 1u)) << 2) | cls;
   // pair[] is the exclusive scan of the heads: an entry that is not a head belongs to pair[i] - 1
   const uint32_t pi = head[i] ? pair[i] : pair[i] - 1u;
-  const uint32_t j = pi - runfirst[run];
+  // Position of the column in its run.  The run is sorted by class, then slot; dealing the
+  // classes out round-robin (rank 0 of every class, rank 1 of every class, ...) makes the four
+  // rows a transposed read takes from LDS in one pass differ in slot & 3, i.e. sit in
+  // different bank quarters, wherever the classes last.
+  const uint32_t qpos = pi - runfirst[run], packed = runclass[run];
+  uint32_t before = 0;
+  for (uint32_t c = 0; c < cls; ++c) before += (packed >> (8 * c)) & 255u;
+  const uint32_t rank = qpos - before;
+  uint32_t j = 0;
+  for (uint32_t c = 0; c < 4; ++c) {
+    const uint32_t nc = (packed >> (8 * c)) & 255u;
+    j += nc < rank ? nc : rank;
+    if (c < cls && nc > rank) ++j;
+  }
   const int64_t step = int64_t(step0[run]) + j / kStepCols;
   const uint32_t kpos = j % kStepCols;
-  if (head[i]) step_slots[step * 16 + kpos] = uint16_t(slot * kRowBytes + ((slot & 3u) << 6));
+  if (head[i]) step_slots[step * 16 + kpos] = uint16_t((slot >> 2) * (4 * kRowBytes) + ((slot & 3u) << 6));
   atomicOr(&step_bits32[step * 16 + (r5 >> 1)], 1u << (kpos + 16u * (r5 & 1u)));
 }
 
@@ -499,6 +520,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct TgArgs {
   const int32_t *grows, *stage_col, *step0;
@@ -535,6 +557,14 @@ __device__ __forceinline__ void tg_dma4(const void* g, uint32_t lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
 }
 
+// LDS by byte offset.  The kernel has no static LDS, so its dynamic segment starts at LDS
+// address 0 and an offset into `smem` is the address itself (formed from the generic pointer,
+// every access pays an add of that zero base).
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* lds(uint32_t off) {
+  return (__attribute__((address_space(3))) T*)(uintptr_t(off));
+}
+
 // One workgroup per (work item, feature slice); 8 wavefronts, wavefront w owns sub-tiles 2 w and 2 w + 1.
 template <int NT>
 __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
@@ -544,7 +574,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int item = blockIdx.x, slice = blockIdx.y;
   const int g = a.item_group[item], s0 = a.item_s0[item], s1 = a.item_s1[item], out = a.item_out[item];
-  const uint32_t lds0 = uint32_t(uintptr_t((__attribute__((address_space(3))) char*)smem));
+  constexpr uint32_t lds0 = 0;   // LDS address of smem: the dynamic segment follows the static one, and there is none
   const char* xs = a.planes + int64_t(slice) * a.slice_bytes;
 
   // Pattern table at LDS offset 0: entry v (a nibble of row bits) holds two dwords of fp16
@@ -574,28 +604,32 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   const uint32_t lane_off = uint32_t(32 * g1 + 8 * p);
   const uint32_t offs_off = uint32_t(kStageRowsBytes + 2 * (8 * h + q));   // this lane's entry of a step's offsets (r = 0)
   const uint32_t bits_off = uint32_t(kStageRowsBytes + kSlotsBytes + 2 * (lane & 31) + h);
-  // source offset of this lane's 16 bytes inside a node's 512-byte slice for the two
-  // slot classes a wavefront's rows alternate between (slot & 3 = h and 2 + h)
-  const uint32_t pc = uint32_t(lane & 31);
-  const uint32_t swz_even = (((pc >> 2) ^ uint32_t(h)) << 6) | ((pc & 3u) << 4);
-  const uint32_t swz_odd = (((pc >> 2) ^ uint32_t(2 + h)) << 6) | ((pc & 3u) << 4);
+  // A row of a stage is 512 bytes: eight 64-byte segments, hi N-tiles 0..3 then lo N-tiles 0..3.
+  // The rows of slots 4 b .. 4 b + 3 form a 2 KB block of LDS, stored segment-major: segment s
+  // of row r at s * 256 + r * 64.  A transposed read takes one segment of four rows per pass;
+  // rows whose slots differ in their low two bits sit in different bank quarters, and the
+  // segments of a row are a constant 256 bytes apart (immediate offsets).  One DMA
+  // instruction brings the hi half of a block, the next its lo half; lane l writes bytes
+  // 16 l .. 16 l + 15 of that kilobyte: segment l >> 4, row (l >> 2) & 3.
+  const uint32_t dma_row = uint32_t(lane >> 2) & 3u;
+  const uint32_t src_off = (uint32_t(lane >> 4) << 6) | (uint32_t(lane & 3) << 4);   // inside the node's hi (or lo) 256 bytes
   const bool small = a.slice_bytes < (int64_t(1) << 32);   // row offsets fit 32 bits
 
-  // Stage s into ring buffer (s - s0) % 2.  Wavefront w brings rows 16 w .. 16 w + 15 (two per
-  // instruction; `col[i]` is the column of row 16 w + 2 i + h for this lane's half h) and a share
+  // Stage s into ring buffer (s - s0) % 2.  Wavefront w brings rows 16 w .. 16 w + 15 (half a
+  // block per instruction; `col[b]` is the column of row 16 w + 4 b + dma_row) and a share
   // of the stage's records: the steps' row offsets and row bits (only as many kilobytes as
   // the stage has steps), the first-step table from this stage on, and the column ids of the
   // following stages, so that the next stage is issued from LDS and not from scalar loads
   // whose latency every wavefront would sit out once per stage.
-  auto issue = [&](int s, const int (&col)[8], int sf32, int steps) {
+  auto issue = [&](int s, const int (&col)[4], int sf32, int steps) {
     const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
     if (!(a.mode & 2)) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(8 * w + i) * 1024u);
-        const uint32_t swz = (i & 1) ? swz_odd : swz_even;
-        if (small) tg_dma16_off(xs, (uint32_t(col[i]) << 9) | swz, dst);
-        else tg_dma16(xs + int64_t(col[i]) * kRowBytes + swz, dst);
+        const uint32_t off = src_off + uint32_t(i & 1) * 256u;
+        if (small) tg_dma16_off(xs, (uint32_t(col[i >> 1]) << 9) | off, dst);
+        else tg_dma16(xs + int64_t(col[i >> 1]) * kRowBytes + off, dst);
       }
     }
     const int64_t sf = sf32;
@@ -624,21 +658,12 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   unsigned long long t_wait = 0, t_issue = 0, t_steps = 0, n_steps = 0;
   const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
   const int ns = s1 - s0;
-  if (ns > 0) {   // the item's first stage: ids by scalar loads (constant address space)
-    typedef int i32x16 __attribute__((ext_vector_type(16)));
-    typedef const __attribute__((address_space(4))) i32x16* c16ptr;
-    typedef const __attribute__((address_space(4))) int32_t* c1ptr;
-    const i32x16 cols = *reinterpret_cast<c16ptr>(uintptr_t(a.stage_col + int64_t(s0) * kStageCols + w * 16));
-    const int sf_first = *reinterpret_cast<c1ptr>(uintptr_t(a.step0 + int64_t(s0) * kSubs));
-    const int sf_second = *reinterpret_cast<c1ptr>(uintptr_t(a.step0 + (int64_t(s0) + 1) * kSubs));
-    int col[8];
+  if (ns > 0) {   // the item's first stage: ids and step counts from global memory
+    int col[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      // (two scalar values and a select: written as a select of vector elements the compiler
-      // makes it a lane-indexed element access, a chain of 16 compares)
-      const int c_even = __builtin_amdgcn_readfirstlane(cols[2 * i]), c_odd = __builtin_amdgcn_readfirstlane(cols[2 * i + 1]);
-      col[i] = h ? c_odd : c_even;
-    }
+    for (int b = 0; b < 4; ++b) col[b] = a.stage_col[int64_t(s0) * kStageCols + 16 * w + 4 * b + dma_row];
+    const int sf_first = __builtin_amdgcn_readfirstlane(a.step0[int64_t(s0) * kSubs]);
+    const int sf_second = __builtin_amdgcn_readfirstlane(a.step0[(int64_t(s0) + 1) * kSubs]);
     issue(s0, col, sf_first, sf_second - sf_first);
   }
 
@@ -656,10 +681,10 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     // issue between the steps, measured slower: the CU's memory pipeline takes ~1400 cycles
     // to accept a stage either way and the earlier it starts the earlier the rows arrive).
     auto issue_next = [&]() {
-      const int* nc = hdr + kHdrBytes / 4 + 16 * w + h;
-      int col[8];
+      const int* nc = hdr + kHdrBytes / 4 + 16 * w + dma_row;
+      int col[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) col[i] = nc[2 * i];
+      for (int b = 0; b < 4; ++b) col[b] = nc[4 * b];
       const int nsf = __builtin_amdgcn_readfirstlane(hdr[kSubs]);
       issue(s0 + k + 1, col, nsf, __builtin_amdgcn_readfirstlane(hdr[2 * kSubs]) - nsf);
     };
@@ -677,23 +702,30 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     // harmless (the bytes are inside the stage buffer, what is read is not used).
     uint32_t rec_o = boff + offs_off + uint32_t(b0) * 32u, rec_b = boff + bits_off + uint32_t(b0) * 64u;
     auto record = [&](uint32_t& off_a, uint32_t& off_b, uint32_t& bt) {
-      off_a = *reinterpret_cast<const uint16_t*>(smem + rec_o);
-      off_b = *reinterpret_cast<const uint16_t*>(smem + rec_o + 8);
-      bt = *reinterpret_cast<const uint8_t*>(smem + rec_b);
+      off_a = *lds<const uint16_t>(rec_o);
+      off_b = *lds<const uint16_t>(rec_o + 8);
+      bt = *lds<const uint8_t>(rec_b);
       rec_o += 32;
       rec_b += 64;
     };
-    auto pattern = [&](uint32_t bt, u32x4& hi, u32x4& lo) {
-      const u32x4 t0 = *reinterpret_cast<const u32x4*>(smem + (bt & 15u) * 16u);
-      const u32x4 t1 = *reinterpret_cast<const u32x4*>(smem + (bt & 0xF0u));
-      hi = u32x4{t0[0], t0[1], t1[0], t1[1]};
-      lo = u32x4{t0[2], t0[3], t1[2], t1[3]};
+    // pattern tile of the lane's row from its 8 column bits: fp16 1.0 (hi plane) / 2^-11 (lo plane)
+    // where the bit of column k = 8 h + i is set; two table entries (one per nibble), each
+    // {hi pair, lo pair}
+    auto pattern_addr = [&](uint32_t bt, uint32_t& ta, uint32_t& tb) {
+      ta = (bt & 15u) << 4;
+      tb = bt & 0xF0u;
     };
-    auto read_tile = [&](uint32_t base_a, uint32_t base_b, int pl, int nt) {
-      const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-          (__attribute__((address_space(3))) hv4*)(smem + ((base_a ^ uint32_t(nt << 6)) + pl * 256)));
-      const hv4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-          (__attribute__((address_space(3))) hv4*)(smem + ((base_b ^ uint32_t(nt << 6)) + pl * 256)));
+    auto pattern_hi = [&](uint32_t ta, uint32_t tb) {
+      const u32x2 x = *lds<const u32x2>(ta), y = *lds<const u32x2>(tb);
+      return u32x4{x[0], x[1], y[0], y[1]};
+    };
+    auto pattern_lo = [&](uint32_t ta, uint32_t tb) {
+      const u32x2 x = *lds<const u32x2>(ta + 8), y = *lds<const u32x2>(tb + 8);
+      return u32x4{x[0], x[1], y[0], y[1]};
+    };
+    auto read_tile = [&](uint32_t base_a, uint32_t base_b, int seg) {   // seg: 0..3 = hi N-tiles, 4..7 = lo
+      const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_a + uint32_t(seg * 256)));
+      const hv4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_b + uint32_t(seg * 256)));
       h8 r;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -703,52 +735,53 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
       return r;
     };
     // Software pipeline over the steps.  Behind every MFMA of step j the reads of the same tile
-    // of X for step j + 1 go out into the registers that MFMA has just consumed, so a read has
-    // seven MFMAs of this wavefront (and the other wavefront's on the SIMD) to arrive; the
-    // record of step j + 2 and the pattern tile of step j + 1 are fetched at the top.  One loop
-    // per sub-tile, so that the accumulators are addressed statically; the prefetch runs across
-    // the seam between the two lists and, harmlessly, one step past the end.
+    // of X for step j + 1 go out into the registers that MFMA has just consumed, and behind the
+    // last MFMA of a plane the pattern tile of step j + 1 for that plane; the record of step
+    // j + 2 is fetched at the top.  Nothing is copied between registers and the segments of a
+    // row are reached by immediate offsets: what bounds this loop is the number of instructions
+    // a wavefront issues beside its MFMAs (an MFMA leaves room for about six).  One loop per
+    // sub-tile, so that the accumulators are addressed statically; the prefetch runs across the
+    // seam between the two lists and, harmlessly, one step past the end.
     if (total > 0 && !(a.mode & 1)) {
-      u32x4 ahi, alo;                             // pattern tile of the current step
+      u32x4 ahi, alo;                             // pattern tiles of the current step
       uint32_t base_a, base_b;                    // row addresses of the step whose tiles are being read
       uint32_t off_a, off_b, bt;                  // record of the step after that
+      uint32_t ta, tb;
       h8 bh[NT], bl[NT];
       record(off_a, off_b, bt);
-      pattern(bt, ahi, alo);
+      pattern_addr(bt, ta, tb);
+      ahi = pattern_hi(ta, tb);
+      alo = pattern_lo(ta, tb);
       base_a = stage_lane + off_a;
       base_b = stage_lane + off_b;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, 0, nt);
+      for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, nt);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, 1, nt);
+      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, NT + nt);
       record(off_a, off_b, bt);
       auto body = [&](auto tt_tag) {
         constexpr int TT = decltype(tt_tag)::value;
-        // step j + 1: its record is here; pattern tile and row addresses
-        u32x4 nhi, nlo;
-        pattern(bt, nhi, nlo);
         base_a = stage_lane + off_a;
         base_b = stage_lane + off_b;
+        pattern_addr(bt, ta, tb);
         record(off_a, off_b, bt);
-        const h8 fhi = __builtin_bit_cast(h8, ahi);
-        const h8 flo = __builtin_bit_cast(h8, alo);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi, bh[nt], acc[TT][nt], 0, 0, 0);
+          acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), bh[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          bh[nt] = read_tile(base_a, base_b, 0, nt);
+          bh[nt] = read_tile(base_a, base_b, nt);
+          if (nt == NT - 1) ahi = pattern_hi(ta, tb);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo, bl[nt], acc[TT][nt], 0, 0, 0);
+          acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), bl[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          bl[nt] = read_tile(base_a, base_b, 1, nt);
+          bl[nt] = read_tile(base_a, base_b, NT + nt);
+          if (nt == NT - 1) alo = pattern_lo(ta, tb);
           __builtin_amdgcn_sched_barrier(0);
         }
-        ahi = nhi;
-        alo = nlo;
       };
       int j = 0;
       for (; j < n0; ++j) body(std::integral_constant<int, 0>{});
@@ -914,8 +947,9 @@ int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
   pb = w.prim_bytes;
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.head, w.pos, 0u, size_t(nnz), rocprim::plus<uint32_t>(), st));
   HIP_TRY(hipMemsetAsync(w.runcount, 0, size_t(w.cap_runs + 1) * 4, st));
+  HIP_TRY(hipMemsetAsync(w.runclass, 0, size_t(w.cap_runs + 1) * 4, st));
   hipLaunchKernelGGL(k_tg_run_counts, blocks_for(nnz), dim3(T), 0, st, nnz, w.keys_b, w.head, w.pos, w.runcount,
-                     w.runfirst);
+                     w.runclass, w.runfirst);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_tg_run_steps, blocks_for(w.cap_runs + 1), dim3(T), 0, st, w.cap_runs, w.counts, w.gstage0, w.G,
                      w.runcount, w.nsteps);
@@ -969,7 +1003,7 @@ int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t sta
   HIP_TRY(hipMemsetAsync(p.step_slots, 0, size_t(steps + kPadSteps) * 32, st));
   HIP_TRY(hipMemsetAsync(p.step_bits, 0, size_t(steps + kPadSteps) * 64, st));
   hipLaunchKernelGGL(k_tg_fill_steps, blocks_for(nnz), dim3(T), 0, st, nnz, w.keys_b, w.head, w.pos, w.runfirst,
-                     w.step0, p.step_slots, reinterpret_cast<uint32_t*>(p.step_bits));
+                     w.runclass, w.step0, p.step_slots, reinterpret_cast<uint32_t*>(p.step_bits));
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_tg_items, blocks_for(p.G), dim3(T), 0, st, p.G, w.gns, w.gstage0, w.nseg, w.first, w.slot0,
                      w.lidx, w.itmp, w.cap_items, p.long_group, p.long_slot, p.long_nseg);

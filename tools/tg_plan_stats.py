@@ -33,3 +33,13 @@ for name, wv in (("w,15-w", wave), ("w,w+8", wave_old)):
 print("sub-tile mean steps by position in group:", [round(v, 2) for v in per.float().mean(0).tolist()])
 tot = per.sum(1).float()
 print("steps per stage: mean %.1f min %d max %d" % (tot.mean().item(), tot.min().item(), tot.max().item()))
+hist = torch.bincount((tot.long() // 8), minlength=17).tolist()
+print("stages by steps per stage (buckets of 8):", hist)
+gst = p["buf"][al(64) + al(G * 512 * 4): al(64) + al(G * 512 * 4) + (G + 1) * 4].view(torch.int32).long()
+gid = torch.repeat_interleave(torch.arange(G, device=dev), gst[1:] - gst[:-1])
+gmax = torch.zeros(G, device=dev).scatter_reduce(0, gid, tot, "amax")
+gsum = torch.zeros(G, device=dev).scatter_add(0, gid, tot)
+for cap in (64, 74, 89, 96, 112):
+    over = tot > cap
+    print(f"cap {cap}: {over.float().mean() * 100:.1f}% of stages hold {tot[over].sum() / tot.sum() * 100:.1f}% of steps; "
+          f"groups with a stage over it: {(gmax > cap).sum().item()} of {G}, holding {gsum[gmax > cap].sum() / tot.sum() * 100:.1f}% of steps")
