@@ -71,7 +71,8 @@ def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic"):
 
 
 @pytest.mark.parametrize("world,order,partition", [(2, 1, "degree_cyclic"), (2, 2, "degree_cyclic"),
-                                                   (3, 3, "degree_cyclic"), (3, 2, "contiguous")])
+                                                   (3, 3, "degree_cyclic"), (3, 2, "contiguous"),
+                                                   (8, 2, "degree_cyclic")])
 def test_row_partitioned_matches_single(world, order, partition):
     from sgnn_amd.graphgen import symmetric_simple_numpy
     n, F = 700, 12
@@ -123,7 +124,7 @@ def _grid_worker(rank, world, fg, port, n, r, c, X, order, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fg,order", [(4, 2, 2), (2, 2, 1), (3, 1, 1)])
+@pytest.mark.parametrize("world,fg,order", [(4, 2, 2), (2, 2, 1), (3, 1, 1), (8, 2, 1)])
 def test_feature_by_row_grid_matches_single(world, fg, order):
     """Ranks on a feature_groups x row_ranks grid: every (row block, feature slice)
     tile is produced exactly once and the assembled result is the single-process one."""

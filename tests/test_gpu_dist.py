@@ -103,3 +103,57 @@ def test_rccl_backend_single_rank(gpu_device):
     assert p.exitcode == 0
     assert same
     assert diff <= 1e-5 * scale
+
+
+def _grid_worker(rank, world, fg, port, n, r, c, X, order, slices, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgnn_amd.dist import PartitionedAdj, grid_layout, make_row_groups
+        dev = torch.device("cuda:0")
+        row_rank, row_world, fgroup, f0, f1 = grid_layout(rank, world, fg, X.shape[1])
+        group = make_row_groups(world, fg)
+        padj = PartitionedAdj.from_coo(torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev), None, n, dev, row_rank,
+                                       row_world, group=group)
+        rows = padj.rows.numpy()
+        Xl = torch.from_numpy(X[rows][:, f0:f1].copy()).to(dev)
+        Y = padj.propagate(Xl, order, slices=slices)
+        Y2 = padj.propagate(Xl, order, slices=slices)      # second call: the kept gather buffers are reused
+        torch.cuda.synchronize()
+        assert torch.equal(Y, Y2)
+        q.put((rank, rows, f0, f1, Y.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("slices", [1, 2])
+def test_four_ranks_two_by_two_grid_on_one_gpu(gpu_device, slices):
+    """2 feature groups x 2 row blocks, all four ranks on cuda:0, the COO handed over on the
+    device (the deal and the column remap then run there): every (row block, feature slice)
+    tile is produced once and the assembled result equals the single-GPU one."""
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    n, F, order, world, fg = 16_000, 200, 2, 4, 2
+    r, c = symmetric_simple_numpy(n, 200_000, seed=6)
+    X = np.random.default_rng(2).standard_normal((n, F)).astype(np.float32)
+    exp = NormAdj.from_coo(r, c, None, n, gpu_device).propagate(torch.from_numpy(X).to(gpu_device), order).cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(k, world, fg, port, n, r, c, X, order, slices, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Y = np.zeros_like(exp)
+    hits = np.zeros(exp.shape, np.int32)
+    for rank, rows, f0, f1, y in got:
+        Y[np.ix_(rows, np.arange(f0, f1))] = y
+        hits[np.ix_(rows, np.arange(f0, f1))] += 1
+    assert (hits == 1).all()
+    assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
