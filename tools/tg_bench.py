@@ -56,14 +56,15 @@ if os.environ.get("TG_CYCLES"):
     adj.use_tilegroup = True
     out = (ctypes.c_ulonglong * 8)()
     fn = lib.sgnn_tilegroup_debug_counters
-    lib.sgnn_tune_set(b"tg_mode", 16)
-    adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
-    adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
-    lib.sgnn_tune_set(b"tg_mode", 0)
-    tot, wait, issue, steps, waves, nsteps, nstages = [out[i] for i in range(7)]
-    print(f"per wavefront: total {tot / waves:.0f} cycles; stage wait {100 * wait / tot:.1f}% issue {100 * issue / tot:.1f}% "
-          f"steps {100 * steps / tot:.1f}%; {steps / nsteps:.0f} cycles per step, {nsteps / nstages:.2f} steps and "
-          f"{wait / nstages:.0f} + {issue / nstages:.0f} + {steps / nstages:.0f} cycles per stage", flush=True)
+    for extra in [int(v) for v in os.environ["TG_CYCLES"].split(",")]:
+        lib.sgnn_tune_set(b"tg_mode", 16 | extra)
+        adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
+        adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
+        lib.sgnn_tune_set(b"tg_mode", 0)
+        tot, wait, issue, steps, waves, nsteps, nstages = [out[i] for i in range(7)]
+        print(f"mode {extra}: per wavefront: total {tot / waves:.0f} cycles; stage wait {100 * wait / tot:.1f}% issue {100 * issue / tot:.1f}% "
+              f"steps {100 * steps / tot:.1f}%; {steps / max(nsteps, 1):.0f} cycles per step, {nsteps / nstages:.2f} steps and "
+              f"{wait / nstages:.0f} + {issue / nstages:.0f} + {steps / nstages:.0f} cycles per stage", flush=True)
 if os.environ.get("TG_MODES"):
     adj.use_tilegroup = True
     for m in (1, 2, 3, 0):
