@@ -430,22 +430,57 @@ __global__ void k_tg_item_place(int64_t items, const uint64_t* __restrict__ keys
 }
 
 // ---- fp16 planes --------------------------------------------------------------------
-__global__ void k_tg_amax(int64_t n, int64_t F, const float* __restrict__ scale_row, const float* __restrict__ X,
-                          int64_t ldx, TgState* __restrict__ state) {
+__global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, const float* __restrict__ scale_row,
+                                                 const float* __restrict__ X, int64_t ldx, TgState* __restrict__ state) {
   uint32_t m = 0;
-  const int64_t total = n * F;
-  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
-    const int64_t r = i / F;
-    const float v = X[r * ldx + (i - r * F)] * (scale_row ? scale_row[r] : 1.0f);
-    const uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu;   // |v|; NaN and inf compare above every finite value
-    m = b > m ? b : m;
+  // a workgroup walks whole rows, four at a time so that four loads are in flight per lane
+  // (lanes along the features, 8-byte loads where the row allows)
+  const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
+  for (int64_t r0 = 4 * int64_t(blockIdx.x); r0 < n; r0 += 4 * int64_t(gridDim.x)) {
+    float sr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sr[i] = (r0 + i < n) ? (scale_row ? scale_row[r0 + i] : 1.0f) : 0.0f;
+    if (pairs) {
+      for (int64_t f = 2 * int64_t(threadIdx.x); f < F; f += 2 * int64_t(blockDim.x)) {
+        float2 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = float2{0.0f, 0.0f};
+          if (r0 + i < n) {
+            const float* row = X + (r0 + i) * ldx;
+            if (f + 1 < F) v[i] = *reinterpret_cast<const float2*>(row + f);
+            else v[i].x = row[f];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t b0 = __builtin_bit_cast(uint32_t, v[i].x * sr[i]) & 0x7FFFFFFFu;   // |v|; NaN and inf compare above every finite value
+          const uint32_t b1 = __builtin_bit_cast(uint32_t, v[i].y * sr[i]) & 0x7FFFFFFFu;
+          m = b0 > m ? b0 : m;
+          m = b1 > m ? b1 : m;
+        }
+      }
+    } else {
+      for (int i = 0; i < 4 && r0 + i < n; ++i)
+        for (int64_t f = threadIdx.x; f < F; f += blockDim.x) {
+          const uint32_t b0 = __builtin_bit_cast(uint32_t, X[(r0 + i) * ldx + f] * sr[i]) & 0x7FFFFFFFu;
+          m = b0 > m ? b0 : m;
+        }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const uint32_t o = uint32_t(__shfl_xor(int(m), off));
     m = o > m ? o : m;
   }
-  if ((threadIdx.x & (kWave - 1)) == 0 && m != 0) atomicMax(&state->amax_bits, m);
+  // one atomic per workgroup: they all hit one word, which takes them one at a time
+  __shared__ uint32_t wave_max[16];
+  if ((threadIdx.x & (kWave - 1)) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (unsigned i = 1; i < blockDim.x / kWave; ++i) m = wave_max[i] > m ? wave_max[i] : m;
+    if (m != 0) atomicMax(&state->amax_bits, m);
+  }
 }
 
 // the power of two that brings amax into [2^14, 2^15)
@@ -458,50 +493,71 @@ __device__ __forceinline__ float tg_scale(uint32_t amax_bits) {
   return __builtin_bit_cast(float, uint32_t(s + 127) << 23);
 }
 
-// planes[slice][node] = 128 halfs hi | 128 halfs lo of (scale_row[node] * X[node, slice]) * scale;
-// one thread per (node, 8 features)
-__global__ __launch_bounds__(256) void k_tg_split(int64_t n, int64_t F, int64_t n_slices,
+// planes[slice][node] = 128 halfs hi | 128 halfs lo of (scale_row[node] * X[node, slice]) * scale.
+// One workgroup walks whole nodes; a thread takes a pair of neighbouring features (one 8-byte
+// read where the row allows it, one 4-byte store into each plane: both coalesced).
+__global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t n_slices,
                                                   const float* __restrict__ scale_row, const float* __restrict__ X,
                                                   int64_t ldx, char* __restrict__ planes, TgState* __restrict__ state) {
-  const int64_t chunks = n_slices * (kSlice / 8);
-  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   const uint32_t amax = state->amax_bits;
   const float scale = tg_scale(amax);
-  if (i == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     state->scale = scale;
     state->inv_scale = 1.0f / scale;
     if (amax >= 0x7F800000u) atomicOr(&state->flag, 1u);
   }
-  if (i >= n * chunks) return;
-  const int64_t node = i / chunks;
-  const int c = int(i - node * chunks);
-  const int slice = c / (kSlice / 8), within = c % (kSlice / 8);
-  const float sr = scale_row ? scale_row[node] : 1.0f;
-  const float* src = X + node * ldx + int64_t(c) * 8;
-  _Float16 hi[8], lo[8];
+  const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
+  const int64_t Fpad = n_slices * kSlice;
   bool bad = false;
   uint32_t tiny = 0;
+  // (one node per pass: the 4-byte stores bound this kernel, more loads in flight do not help)
+  for (int64_t node = blockIdx.x; node < n; node += gridDim.x) {
+    const float sr = scale_row ? scale_row[node] : 1.0f;
+    const float* row = X + node * ldx;
+    for (int64_t f = 2 * int64_t(threadIdx.x); f < Fpad; f += 2 * int64_t(blockDim.x)) {
+      float x[2] = {0.0f, 0.0f};
+      if (f + 1 < F && pairs) {
+        const float2 v = *reinterpret_cast<const float2*>(row + f);
+        x[0] = v.x;
+        x[1] = v.y;
+      } else {
+        if (f < F) x[0] = row[f];
+        if (f + 1 < F) x[1] = row[f + 1];
+      }
+      _Float16 hi[2], lo[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float x = (int64_t(c) * 8 + j < F) ? src[j] * sr : 0.0f;   // the reference's scaling (utils.py:93), fp32
-    const float xs = x * scale;
-    const _Float16 h = _Float16(xs);
-    const float r = xs - float(h);
-    const _Float16 l = _Float16(r * 2048.0f);
-    const float back = float(h) + float(l) * (1.0f / 2048.0f);
-    // hi + lo / 2048 carries 22 bits of the input down to the spacing of the lo plane's
-    // subnormals (2^-35 here, 2^-50 of the largest magnitude); `!(<=)` also catches NaN
-    const float ax = __builtin_fabsf(xs);
-    bad |= !(__builtin_fabsf(xs - back) <= __builtin_fmaxf(ax * 4.8e-7f, 3.0e-11f));
-    tiny += (x != 0.0f && ax < 1.9e-6f) ? 1u : 0u;   // below 2^-19 (or flushed to 0): fewer than 17 of its bits survive
-    hi[j] = h;
-    lo[j] = l;
+      for (int j = 0; j < 2; ++j) {
+        const float xv = x[j] * sr;                  // the reference's scaling (utils.py:93), fp32
+        const float xs = xv * scale;
+        const _Float16 h = _Float16(xs);
+        const float r = xs - float(h);
+        const _Float16 l = _Float16(r * 2048.0f);
+        const float back = float(h) + float(l) * (1.0f / 2048.0f);
+        // hi + lo / 2048 carries 22 bits of the input down to the spacing of the lo plane's
+        // subnormals (2^-35 here, 2^-50 of the largest magnitude); `!(<=)` also catches NaN
+        const float ax = __builtin_fabsf(xs);
+        bad |= !(__builtin_fabsf(xs - back) <= __builtin_fmaxf(ax * 4.8e-7f, 3.0e-11f));
+        tiny += (xv != 0.0f && ax < 1.9e-6f) ? 1u : 0u;   // below 2^-19 (or flushed to 0): fewer than 17 of its bits survive
+        hi[j] = h;
+        lo[j] = l;
+      }
+      const int64_t slice = f / kSlice;
+      const int within = int(f % kSlice);
+      char* dst = planes + ((slice * n + node) * kRowBytes) + within * 2;
+      *reinterpret_cast<uint32_t*>(dst) =
+          uint32_t(__builtin_bit_cast(uint16_t, hi[0])) | (uint32_t(__builtin_bit_cast(uint16_t, hi[1])) << 16);
+      *reinterpret_cast<uint32_t*>(dst + kRowBytes / 2) =
+          uint32_t(__builtin_bit_cast(uint16_t, lo[0])) | (uint32_t(__builtin_bit_cast(uint16_t, lo[1])) << 16);
+    }
   }
-  if (tiny) atomicAdd(&state->tiny, tiny);
-  char* dst = planes + ((int64_t(slice) * n + node) * kRowBytes) + within * 16;
-  *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(hi);
-  *reinterpret_cast<uint4*>(dst + 256) = *reinterpret_cast<const uint4*>(lo);
-  if (bad) atomicOr(&state->flag, 1u);
+  // one atomic per wavefront
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
+  const bool any_bad = __any(bad);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    if (tiny) atomicAdd(&state->tiny, tiny);
+    if (any_bad) atomicOr(&state->flag, 1u);
+  }
 }
 
 // A continuous distribution leaves a handful of such elements among 10^8 (they change a sum
@@ -845,24 +901,31 @@ __global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
   if (a.state->flag != 0) return;
   const int li = blockIdx.x;
   const int g = a.long_group[li], slot = a.long_slot[li], nseg = a.long_nseg[li];
+  const int64_t stride = int64_t(kRows) * a.Fpad;
   for (int rr = blockIdx.y; rr < kRows; rr += gridDim.y) {
     const int row = a.grows[int64_t(g) * kRows + rr];
     if (row < 0) continue;
     const bool scale = a.dinv_row != nullptr;
     const float dr = scale ? a.dinv_row[row] : 1.0f;
     const float cr = a.corr != nullptr ? a.corr[row] * (a.dinv_col != nullptr ? a.dinv_col[row] : 1.0f) : 0.0f;
-    for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
-      const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f;
-      const int64_t stride = int64_t(kRows) * a.Fpad;
-      float s = 0.0f;
-      for (int k = 0; k < nseg; ++k) s += pp[k * stride];
-      if (a.corr != nullptr) s = fmaf(a.w_off, s, cr * a.X[int64_t(row) * a.ldx + f]);
-      else if (a.w_off != 1.0f) s *= a.w_off;
-      if (scale) {
-        s = s * dr;
-        if (a.epilogue == SGNN_EPI_SCALE_ROW2) s = s * dr;
+    // four features per thread (the partial rows are padded to whole slices and 16-byte aligned)
+    for (int f4 = 4 * threadIdx.x; f4 < a.F; f4 += 4 * blockDim.x) {
+      const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f4;
+      f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int k = 0; k < nseg; ++k) s += *reinterpret_cast<const f32x4*>(pp + k * stride);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = f4 + j;
+        if (f >= a.F) break;
+        float y = s[j];
+        if (a.corr != nullptr) y = fmaf(a.w_off, y, cr * a.X[int64_t(row) * a.ldx + f]);
+        else if (a.w_off != 1.0f) y *= a.w_off;
+        if (scale) {
+          y = y * dr;
+          if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+        }
+        a.Y[int64_t(row) * a.ldy + f] = y;
       }
-      a.Y[int64_t(row) * a.ldy + f] = s;
     }
   }
 }
@@ -1036,10 +1099,13 @@ int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, 
   const int64_t slices = (F + kSlice - 1) / kSlice;
   TgState* s = static_cast<TgState*>(state);
   HIP_TRY(hipMemsetAsync(s, 0, sizeof(TgState), st));
-  hipLaunchKernelGGL(k_tg_amax, dim3(2048), dim3(256), 0, st, n_cols, F, scale_row, X, ldx, s);
+  // a thread per pair of features of a row: as many wavefronts as a row (padded to whole slices) needs
+  const int64_t pairs = slices * kSlice / 2;
+  const unsigned T = unsigned(pairs >= 1024 ? 1024 : (pairs + kWave - 1) / kWave * kWave);
+  const unsigned row_blocks = unsigned(n_cols < 16384 ? n_cols : 16384);
+  hipLaunchKernelGGL(k_tg_amax, dim3(row_blocks < 2048 ? row_blocks : 2048), dim3(T), 0, st, n_cols, F, scale_row, X, ldx, s);
   HIP_TRY(hipGetLastError());
-  const int64_t threads = n_cols * slices * (kSlice / 8);
-  hipLaunchKernelGGL(k_tg_split, blocks_for(threads), dim3(256), 0, st, n_cols, F, slices, scale_row, X, ldx,
+  hipLaunchKernelGGL(k_tg_split, dim3(row_blocks), dim3(256), 0, st, n_cols, F, slices, scale_row, X, ldx,
                      static_cast<char*>(planes), s);
   HIP_TRY(hipGetLastError());
   const int64_t lim = (n_cols * F) >> 20;
@@ -1076,6 +1142,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   if (planes_bytes < sgnn_tilegroup_planes_bytes(n_cols, F)) return fail(SGNN_ERR_WORKSPACE, "planes buffer too small");
   if (partial_slots > 0 && (!workspace || workspace_bytes < sgnn_spmm_tilegroup_workspace_bytes(partial_slots, F)))
     return fail(SGNN_ERR_WORKSPACE, "tile-group spmm workspace too small");
+  if (reinterpret_cast<uintptr_t>(workspace) % 16) return fail(SGNN_ERR_INVALID, "workspace must be 16-byte aligned");
   const int64_t slices = (F + kSlice - 1) / kSlice;
   if (slices > 65535) return fail(SGNN_ERR_INVALID, "too many feature slices for one launch");
   TgArgs a{};
