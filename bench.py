@@ -297,6 +297,9 @@ def main():
     ap.add_argument("--feature-groups", type=int, default=0,
                     help="N > 1: extra grids to probe beside the row partition: 0 = every divisor of N, 1 = none, "
                          "k = only k feature groups")
+    ap.add_argument("--exchange", default="auto", choices=["allgather", "referenced", "auto"],
+                    help="N > 1: rows of X a rank receives per hop: all of them (one all-gather), only the ones its "
+                         "block references (all-to-all), or the latter where it saves at least 40 %% of the bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the other shapes and the SGNN epoch")
     ap.add_argument("--epoch-iters", type=int, default=10000,
@@ -362,13 +365,14 @@ def main():
             row_rank, row_world, fgroup, f0, f1 = grid_layout(rank, world, fg, F)
             group = make_row_groups(world, fg)
             t0 = time.perf_counter()
-            padj = PartitionedAdj.from_coo(row, col, None, n, device, row_rank, row_world, group=group)
+            padj = PartitionedAdj.from_coo(row, col, None, n, device, row_rank, row_world, group=group,
+                                           exchange=args.exchange)
             torch.cuda.synchronize()
             build_ms = (time.perf_counter() - t0) * 1e3
             Xl = X[padj.rows.to(device)][:, f0:f1].contiguous()
             schedules = [1]
             want = max(1, args.slices)
-            if row_world > 1 and want > 1:
+            if row_world > 1 and want > 1 and padj.halo is None:     # (the referenced-rows exchange is not sliced)
                 # the overlapped (feature-sliced) exchange competes only if it reproduces
                 # the plain one; every rank of the job takes the same decision
                 ok = torch.ones(1, device=device)
@@ -390,8 +394,12 @@ def main():
                         "exchange_slices": sl, "adjacency_build_ms": build_ms, "nnz": padj.global_nnz,
                         "max_deg": padj.global_max_degree,
                         "exchange_ranks": dist.get_world_size(group) if row_world > 1 else 1,
-                        "exchange_bytes_per_rank_per_hop": padj.max_rows * row_world * ((f1 - f0 + 3) // 4 * 4) * 4
-                                                           if row_world > 1 else 0}
+                        "exchange": "none" if row_world == 1 else
+                                    ("all_gather_into_tensor" if padj.halo is None else "all_to_all_single of referenced rows"),
+                        "exchange_bytes_per_rank_per_hop":
+                            0 if row_world == 1 else
+                            (padj.max_rows * row_world if padj.halo is None else padj.halo["n_recv"])
+                            * ((f1 - f0 + 3) // 4 * 4) * 4}
                 out.append(((lambda sl=sl: padj.propagate(Xl, args.order, slices=sl)), info))
             return out
 
@@ -434,7 +442,7 @@ def main():
         del row, col, X
         nnz, max_deg = info.pop("nnz"), info.pop("max_deg")
         extra.update(info)
-        extra["collective"] = (f"all_gather_into_tensor among {info['exchange_ranks']} ranks, backend "
+        extra["collective"] = (f"{info['exchange']} among {info['exchange_ranks']} ranks, backend "
                                f"{dist.get_backend()} ({'gloo rehearsal on one GPU' if rehearsal else 'RCCL'}), "
                                f"world size {dist.get_world_size()}")
         if rank == 0:

@@ -26,6 +26,13 @@ every rank's rows are contiguous.  Pre-scaling before the exchange means
 into column slices and the all-gather of slice s+1 runs on a side stream while
 slice s is multiplied, which hides most of the exchange behind the SpMM.
 
+``exchange="referenced"`` replaces the all-gather by an all-to-all of exactly the rows each
+rank's block references (the index lists are fixed at build time; columns are renumbered into
+own rows followed by the received rows in rank order).  It moves ``referenced / all`` of the
+bytes: 82 % on the Reddit shape at 8 ranks, where it is not worth its extra gather pass, but
+39 % on ogbn-products and 25 % on R-MAT 10 M; ``exchange="auto"`` picks it when at most 60 %
+of the rows a rank would receive are used.
+
 The columns of X are independent, so the feature dimension can be split over ranks
 with no exchange at all.  ``grid_layout`` arranges the ranks as ``feature_groups`` x
 ``row_ranks``: a rank owns one block of rows and one slice of features, and the
@@ -41,7 +48,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .norm_adj import NormAdj
+from .norm_adj import NormAdj, tilegroup_build, tilegroup_hop
 
 
 def grid_layout(rank, world, feature_groups, F, align=2):
@@ -139,7 +146,7 @@ class PartitionedAdj:
     caller hands ``X[rows]`` to ``propagate`` and gets ``Y[rows]`` back."""
 
     def __init__(self, local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group=None,
-                 splits=None):
+                 splits=None, halo=None):
         self.local = local                      # block over (rows_local x padded columns)
         self.rows, self.rank, self.world, self.n = rows, rank, world, n
         self.n_local = int(rows.numel())
@@ -149,6 +156,8 @@ class PartitionedAdj:
         self.row_end = splits[rank + 1] if splits is not None else None
         self.global_nnz, self.global_max_degree = global_nnz, global_max_degree
         self.group = group
+        # referenced-rows exchange: dict(send_idx, send_counts, recv_counts, n_recv) or None (all-gather)
+        self.halo = halo
         self._gather = {}
         self._slice_bufs = {}
         self._comm_stream = None
@@ -156,7 +165,7 @@ class PartitionedAdj:
     # ------------------------------------------------------------------ build
     @classmethod
     def from_coo(cls, row, col, val, n, device, rank, world, group=None, local_factory=None,
-                 partition="degree_cyclic"):
+                 partition="degree_cyclic", exchange="allgather"):
         """Every rank passes the same COO (entries of other ranks' rows are dropped
         here).  ``local_factory`` is a test hook that builds the local block from
         ``(row_padded, col_padded, val, n_rows, n_padded, first_padded_row)``; the
@@ -198,18 +207,51 @@ class PartitionedAdj:
         lrow, lcol = prow[mine], pad[col[mine]]
         lval = None if val is None else torch.as_tensor(val)[mine]
         n_pad = max_rows * world
+        if exchange not in ("allgather", "referenced", "auto"):
+            raise ValueError(f"unknown exchange {exchange!r}")
+        halo = None
+        if exchange != "allgather" and world > 1:
+            # rows of other ranks this rank's block references, in padded (owner-major) order
+            foreign = (lcol < r0) | (lcol >= r0 + max_rows)
+            need = torch.unique(lcol[foreign])
+            use = exchange == "referenced" or need.numel() <= 0.6 * (world - 1) * max_rows
+            if exchange == "auto" and dist.is_initialized():
+                # every rank of the exchange must take the same decision
+                flag = torch.tensor([1 if use else 0], dtype=torch.int32,
+                                    device="cpu" if dist.get_backend(group) == "gloo" else device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                use = bool(flag.item())
+            if use:
+                pcol = pad[col]
+                # rows of this rank's block that each other rank references: key = (target, position)
+                theirs = ((prow < r0) | (prow >= r0 + max_rows)) & (pcol >= r0) & (pcol < r0 + max_rows)
+                key = torch.unique((prow[theirs] // max_rows) * max_rows + (pcol[theirs] - r0))
+                send_counts = torch.bincount(key // max_rows, minlength=world).tolist()
+                recv_counts = torch.bincount(need // max_rows, minlength=world).tolist()
+                halo = dict(send_idx=(key % max_rows).contiguous(), send_counts=send_counts, recv_counts=recv_counts,
+                            n_recv=int(need.numel()))
+                # compact column space: own rows at [0, max_rows), received rows behind them
+                own = ~foreign
+                ccol = torch.empty_like(lcol)
+                ccol[own] = lcol[own] - r0
+                ccol[foreign] = max_rows + torch.searchsorted(need, lcol[foreign])
+                lrow, lcol = lrow - r0, ccol
+                n_pad, r0 = max_rows + int(need.numel()), 0
+                del pcol, theirs, key
         if local_factory is not None:
             local = local_factory(lrow, lcol, lval, int(rows.numel()), n_pad, r0)
         else:
             local = _LocalBlock.build(lrow, lcol, lval, n_pad, r0, r0 + int(rows.numel()), device)
-        return cls(local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group, splits)
+        if halo is not None:
+            halo["send_idx"] = halo["send_idx"].to(device)
+        return cls(local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group, splits, halo)
 
     # ------------------------------------------------------------------ apply
     def _buffers(self, F, device, dtype):
         key = (F, device, dtype)
         b = self._gather.get(key)
         if b is None:
-            rows = self.max_rows * self.world
+            rows = self.max_rows * self.world if self.halo is None else self.max_rows + self.halo["n_recv"]
             Fp = (F + 3) // 4 * 4      # rows on 16-byte boundaries for the row-group kernel's loads
             b = [torch.zeros((rows, Fp), dtype=dtype, device=device) for _ in range(2)]
             self._gather = {key: b}
@@ -229,6 +271,19 @@ class PartitionedAdj:
         inp = piece if piece.is_cuda else piece.clone()
         dist.all_gather_into_tensor(full.view(-1), inp.reshape(-1), group=self.group)
 
+    def _exchange_referenced(self, full):
+        """All-to-all of the referenced rows: the rows other ranks need are gathered out of this
+        rank's block (first ``max_rows`` rows of ``full``) and what this rank needs lands behind it."""
+        h = self.halo
+        send = full[:self.max_rows].index_select(0, h["send_idx"])
+        recv = full[self.max_rows:]
+        if full.is_cuda and dist.get_backend(self.group) == "gloo":      # tests: several ranks on one GPU
+            host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(host, send.cpu(), h["recv_counts"], h["send_counts"], group=self.group)
+            recv.copy_(host)
+            return
+        dist.all_to_all_single(recv, send, h["recv_counts"], h["send_counts"], group=self.group)
+
     def propagate(self, X_local, order=1, slices=1):
         """``A_hat^order . X`` for the local rows; X_local = this rank's rows of X.
         Returns this rank's rows of the result."""
@@ -239,10 +294,10 @@ class PartitionedAdj:
         if X_local.shape[0] != rows:
             raise ValueError(f"rank {self.rank} owns {rows} rows, got {X_local.shape[0]}")
         F = X_local.shape[1]
-        if slices > 1 and X_local.is_cuda:
+        if slices > 1 and X_local.is_cuda and self.halo is None:
             return self._propagate_sliced(X_local, order, slices)
         bufs = self._buffers(F, X_local.device, X_local.dtype)
-        lo = self.rank * self.max_rows
+        lo = self.rank * self.max_rows if self.halo is None else 0
         src = X_local
         out = None
         for h in range(order):
@@ -251,7 +306,10 @@ class PartitionedAdj:
             if h == 0:
                 self.local.scale_rows_into(src, piece[:rows, :F])       # utils.py:93
             # later hops: the previous epilogue already wrote the doubly scaled rows into `piece`
-            self._all_gather(full, piece)
+            if self.halo is None:
+                self._all_gather(full, piece)
+            else:
+                self._exchange_referenced(full)
             last = h == order - 1
             if last:
                 out = torch.empty((rows, F), dtype=X_local.dtype, device=X_local.device)
@@ -323,6 +381,10 @@ class _LocalBlock:
         self.x_row_offset = int(x_row_offset)   # where the block's own rows sit in the gathered X
         self._plans = {}
         self._ws = {}
+        # tile-group (matrix-core) kernel on the rank's rows: None = where it pays (the same test
+        # as NormAdj applies), True / False force it on / off
+        self.use_tilegroup = None
+        self._tg = None
 
     @classmethod
     def build(cls, lrow, lcol, lval, n_pad, r0, r1, device):
@@ -380,6 +442,17 @@ class _LocalBlock:
             self._plans[R] = plan
         return plan
 
+    def _tilegroup_plan(self, F):
+        a = self.adj
+        if self.use_tilegroup is False or a.nnz == 0 or a.w_off is None or a.corr is not None:
+            return None        # (a diagonal of its own would need the block's rows of X at an offset)
+        auto = self.use_tilegroup is None
+        if auto and (F < 96 or self.n_rows < 8192 or a.nnz < 32 * self.n_rows):
+            return None
+        if self._tg is None:
+            self._tg = tilegroup_build(self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a.device, auto)
+        return self._tg or None
+
     def spmm_into(self, full, out, final):
         """out[rows_local, F] = dinv . (block . full), or (dinv . s) . dinv when not final."""
         lib = _lib.load()
@@ -387,6 +460,17 @@ class _LocalBlock:
         F = full.shape[1]
         dev = full.device
         epi = _lib.EPI_SCALE_ROW if final else _lib.EPI_SCALE_ROW2
+        tg = self._tilegroup_plan(F)
+        if tg is not None:
+            # the gathered rows arrive scaled (utils.py:93 was applied before the exchange): split as they are
+            nbytes = lib.sgnn_spmm_workspace_bytes(self.n_rows, a.nnz, F)
+            ws = self._ws.get(("csr", F))
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+                self._ws[("csr", F)] = ws
+            tilegroup_hop(tg, self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a._vals, F, full, full.stride(0),
+                          out, out.stride(0), self.dinv, None, a.w_off, None, epi, ws, dev)
+            return
         aligned = full.data_ptr() % 16 == 0 and full.stride(0) % 4 == 0      # 16-byte row loads
         plan = self._plan(F) if aligned else None
         if plan is not None:

@@ -55,6 +55,60 @@ def weight_structure(n, rowptr, colidx, vals):
     return False, w, corr
 
 
+# a fetched row of X must serve at least this many stored entries, on average over the
+# groups of 512 rows, for the tile-group kernel to be chosen automatically
+TILEGROUP_MIN_SHARING = 4.0
+
+
+def tilegroup_build(n_rows, n_cols, nnz, rowptr, colidx, device, auto=True):
+    """Tile-group plan of an ``n_rows x n_cols`` CSR pattern (``sgnn_tilegroup_analyze`` +
+    ``_fill``), or ``False`` when ``auto`` and its rows share too few columns to pay for it."""
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        st = _lib.current_stream(device)
+        wbytes = lib.sgnn_tilegroup_build_workspace_bytes(n_rows, nnz)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=device)
+        _lib.check(lib.sgnn_tilegroup_analyze(n_rows, n_cols, nnz, _lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(ws),
+                                              wbytes, st))
+        merged, stages, steps, items, slots, n_long = (int(v) for v in ws[:48].view(torch.int64).cpu())
+        if auto and merged * TILEGROUP_MIN_SHARING > nnz:
+            return False
+        pbytes = lib.sgnn_tilegroup_plan_bytes(n_rows, stages, steps, items, n_long)
+        buf = torch.empty(pbytes, dtype=torch.uint8, device=device)
+        _lib.check(lib.sgnn_tilegroup_fill(n_rows, n_cols, nnz, stages, steps, items, n_long, _lib.ptr(buf), pbytes,
+                                           _lib.ptr(ws), wbytes, st))
+        torch.cuda.current_stream(device).synchronize()      # the workspace goes away below
+        del ws
+    return dict(buf=buf, bytes=pbytes, merged=merged, stages=stages, steps=steps, items=items, slots=slots,
+                n_long=n_long, bufs={})
+
+
+def tilegroup_hop(plan, n_rows, n_cols, nnz, rowptr, colidx, vals, F, X, ldx, Y, ldy, dinv_row, split_scale, w_off, corr,
+                  epilogue, csr_ws, device):
+    """One hop through the tile-group kernel: split X (times ``split_scale`` per row if given) into
+    fp16 planes, multiply; the plain CSR kernel stands behind it for operands the planes cannot
+    represent.  The per-width buffers (planes, partial rows, state words) live in ``plan["bufs"]``."""
+    lib = _lib.load()
+    bufs = plan["bufs"].get(F)
+    if bufs is None:
+        pl_bytes = lib.sgnn_tilegroup_planes_bytes(n_cols, F)
+        ws_bytes = lib.sgnn_spmm_tilegroup_workspace_bytes(plan["slots"], F)
+        bufs = dict(planes=torch.empty(pl_bytes, dtype=torch.uint8, device=device), pl_bytes=pl_bytes,
+                    ws=torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=device),
+                    state=torch.zeros(64, dtype=torch.int32, device=device))
+        plan["bufs"] = {F: bufs}
+    st = _lib.current_stream(device)
+    _lib.check(lib.sgnn_tilegroup_split_f32(n_cols, F, _lib.ptr(split_scale), _lib.ptr(X), ldx,
+                                            _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), st))
+    _lib.check(lib.sgnn_spmm_tilegroup_f32(
+        n_rows, n_cols, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"],
+        plan["slots"], plan["n_long"], _lib.ptr(dinv_row), float(w_off), _lib.ptr(corr),
+        _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), _lib.ptr(Y), ldy, int(epilogue),
+        _lib.ptr(bufs["ws"]), bufs["ws"].numel(), nnz, _lib.ptr(rowptr), _lib.ptr(colidx),
+        _lib.ptr(vals), _lib.ptr(split_scale), _lib.ptr(X), ldx, _lib.ptr(csr_ws), csr_ws.numel(), st))
+    return bufs
+
+
 def _require_gpu(device):
     device = torch.device(device)
     if device.type != "cuda":
@@ -243,9 +297,7 @@ class NormAdj:
             self._plans[R] = plan
         return plan
 
-    # a fetched row of X must serve at least this many stored entries, on average over the
-    # groups of 512 rows, for the tile-group kernel to be chosen automatically
-    TILEGROUP_MIN_SHARING = 4.0
+    TILEGROUP_MIN_SHARING = TILEGROUP_MIN_SHARING
 
     def _tilegroup_plan(self, F):
         """Tile-group plan, or None when that kernel does not apply (off-diagonal weights that
@@ -258,51 +310,15 @@ class NormAdj:
         if auto and (F < 96 or self.n < 8192 or self.nnz < 32 * self.n):
             return None
         if self._tg is None:
-            lib = _lib.load()
-            with torch.cuda.device(self.device):
-                st = _lib.current_stream(self.device)
-                wbytes = lib.sgnn_tilegroup_build_workspace_bytes(self.n, self.nnz)
-                ws = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
-                _lib.check(lib.sgnn_tilegroup_analyze(self.n, self.n, self.nnz, _lib.ptr(self.rowptr),
-                                                      _lib.ptr(self.colidx), _lib.ptr(ws), wbytes, st))
-                merged, stages, steps, items, slots, n_long = (int(v) for v in ws[:48].view(torch.int64).cpu())
-                if auto and merged * self.TILEGROUP_MIN_SHARING > self.nnz:
-                    self._tg = False
-                else:
-                    pbytes = lib.sgnn_tilegroup_plan_bytes(self.n, stages, steps, items, n_long)
-                    buf = torch.empty(pbytes, dtype=torch.uint8, device=self.device)
-                    _lib.check(lib.sgnn_tilegroup_fill(self.n, self.n, self.nnz, stages, steps, items, n_long,
-                                                       _lib.ptr(buf), pbytes, _lib.ptr(ws), wbytes, st))
-                    torch.cuda.current_stream(self.device).synchronize()      # the workspace goes away below
-                    self._tg = dict(buf=buf, bytes=pbytes, merged=merged, stages=stages, steps=steps, items=items,
-                                    slots=slots, n_long=n_long)
-                del ws
+            self._tg = tilegroup_build(self.n, self.n, self.nnz, self.rowptr, self.colidx, self.device, auto)
         return self._tg or None
 
     def _tilegroup_hop(self, plan, X, ldx, Y, ldy, F, scale_rows, scale_cols, epilogue):
-        """One hop through the tile-group kernel: split X (times dinv per row if ``scale_cols``)
-        into fp16 planes, multiply; the plain CSR kernel stands behind it for operands the
-        planes cannot represent."""
-        lib = _lib.load()
-        bufs = self._tg_bufs.get(F)
-        if bufs is None:
-            pl_bytes = lib.sgnn_tilegroup_planes_bytes(self.n, F)
-            ws_bytes = lib.sgnn_spmm_tilegroup_workspace_bytes(plan["slots"], F)
-            bufs = dict(planes=torch.empty(pl_bytes, dtype=torch.uint8, device=self.device), pl_bytes=pl_bytes,
-                        ws=torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=self.device),
-                        state=torch.zeros(64, dtype=torch.int32, device=self.device))
-            self._tg_bufs = {F: bufs}
-        csr_ws = self._workspace(F)
-        st = _lib.current_stream(self.device)
-        dinv = _lib.ptr(self.dinv)
-        _lib.check(lib.sgnn_tilegroup_split_f32(self.n, F, dinv if scale_cols else None, _lib.ptr(X), ldx,
-                                                _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), st))
-        _lib.check(lib.sgnn_spmm_tilegroup_f32(
-            self.n, self.n, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"],
-            plan["slots"], plan["n_long"], dinv if scale_rows else None, float(self.w_off), _lib.ptr(self.corr),
-            _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), _lib.ptr(Y), ldy, int(epilogue),
-            _lib.ptr(bufs["ws"]), bufs["ws"].numel(), self.nnz, _lib.ptr(self.rowptr), _lib.ptr(self.colidx),
-            _lib.ptr(self._vals), dinv if scale_cols else None, _lib.ptr(X), ldx, _lib.ptr(csr_ws), csr_ws.numel(), st))
+        """One hop through the tile-group kernel (``tilegroup_hop``) on the whole matrix."""
+        bufs = tilegroup_hop(plan, self.n, self.n, self.nnz, self.rowptr, self.colidx, self._vals, F, X, ldx, Y, ldy,
+                             self.dinv if scale_rows else None, self.dinv if scale_cols else None, self.w_off,
+                             self.corr, epilogue, self._workspace(F), self.device)
+        self._tg_bufs = {F: bufs}
 
     def _rowgroup_ws(self, plan, F):
         ws = plan["ws"].get(F)

@@ -51,15 +51,17 @@ class OracleBlock:
         out.copy_(torch.from_numpy(y.astype(np.float32)))
 
 
-def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic"):
+def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic", exchange="allgather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sgnn_amd.dist import PartitionedAdj
         padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, "cpu", rank, world,
-                                       local_factory=OracleBlock, partition=partition)
+                                       local_factory=OracleBlock, partition=partition, exchange=exchange)
         rows = padj.rows.numpy()
+        if exchange == "referenced":
+            assert padj.halo is not None and sum(padj.halo["recv_counts"]) == padj.halo["n_recv"]
         if partition == "contiguous":
             assert np.array_equal(rows, np.arange(padj.row_begin, padj.row_end))
         Xl = torch.from_numpy(X[rows].copy())
@@ -70,10 +72,12 @@ def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,order,partition", [(2, 1, "degree_cyclic"), (2, 2, "degree_cyclic"),
-                                                   (3, 3, "degree_cyclic"), (3, 2, "contiguous"),
-                                                   (8, 2, "degree_cyclic")])
-def test_row_partitioned_matches_single(world, order, partition):
+@pytest.mark.parametrize("world,order,partition,exchange", [
+    (2, 1, "degree_cyclic", "allgather"), (2, 2, "degree_cyclic", "allgather"), (3, 3, "degree_cyclic", "allgather"),
+    (3, 2, "contiguous", "allgather"), (8, 2, "degree_cyclic", "allgather"),
+    (2, 2, "degree_cyclic", "referenced"), (4, 3, "degree_cyclic", "referenced"), (3, 2, "contiguous", "referenced"),
+    (8, 2, "degree_cyclic", "auto")])
+def test_row_partitioned_matches_single(world, order, partition, exchange):
     from sgnn_amd.graphgen import symmetric_simple_numpy
     n, F = 700, 12
     r, c = symmetric_simple_numpy(n, 4000, seed=3)
@@ -83,7 +87,7 @@ def test_row_partitioned_matches_single(world, order, partition):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, q, partition))
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, q, partition, exchange))
              for k in range(world)]
     for p in procs:
         p.start()

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, r, c, X, order, slices, q, w=None):
+def _worker(rank, world, port, n, r, c, X, order, slices, q, w=None, exchange="allgather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -27,7 +27,9 @@ def _worker(rank, world, port, n, r, c, X, order, slices, q, w=None):
         from sgnn_amd.dist import PartitionedAdj
         dev = torch.device("cuda:0")
         val = None if w is None else torch.full((r.size,), w, dtype=torch.float32)
-        padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), val, n, dev, rank, world)
+        padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), val, n, dev, rank, world,
+                                       exchange=exchange)
+        assert (padj.halo is not None) == (exchange == "referenced")
         rows = padj.rows.numpy()
         Xl = torch.from_numpy(X[rows].copy()).to(dev)
         Y = padj.propagate(Xl, order, slices=slices)
@@ -38,9 +40,11 @@ def _worker(rank, world, port, n, r, c, X, order, slices, q, w=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("F,order,slices,w", [(96, 1, 1, None), (602, 2, 1, None), (602, 2, 2, None), (7, 2, 1, None),
-                                              (128, 2, 1, 2.0)])
-def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w):
+@pytest.mark.parametrize("F,order,slices,w,exchange", [
+    (96, 1, 1, None, "allgather"), (602, 2, 1, None, "allgather"), (602, 2, 2, None, "allgather"),
+    (7, 2, 1, None, "allgather"), (128, 2, 1, 2.0, "allgather"),
+    (100, 3, 1, None, "referenced"), (128, 2, 1, 2.0, "referenced")])
+def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w, exchange):
     from sgnn_amd import NormAdj
     from sgnn_amd.graphgen import symmetric_simple_numpy
     n = 20_000
@@ -52,7 +56,8 @@ def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, slices, q, w)) for k in range(world)]
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, slices, q, w, exchange))
+             for k in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
@@ -63,6 +68,54 @@ def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w):
     for rank, rows, y in got:
         Y[rows] = y
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
+
+
+def _tg_worker(rank, world, port, n, E, F, order, slices, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgnn_amd import NormAdj
+        from sgnn_amd.dist import PartitionedAdj
+        from sgnn_amd.graphgen import rmat_undirected_device
+        dev = torch.device("cuda:0")
+        row, col = rmat_undirected_device(n, E, seed=5, device=dev)
+        g = torch.Generator(device=dev); g.manual_seed(9)
+        X = torch.randn(n, F, device=dev, generator=g)
+        padj = PartitionedAdj.from_coo(row, col, None, n, dev, rank, world)
+        rows = padj.rows.to(dev)
+        Y = padj.propagate(X[rows].contiguous(), order, slices=slices)
+        used = bool(padj.local._tg)
+        ref = NormAdj.from_coo(row, col, None, n, dev)
+        ref.use_tilegroup = False
+        exp = ref.propagate(X, order)[rows]
+        scale = ref.propagate(X.abs(), order)[rows]
+        torch.cuda.synchronize()
+        q.put((rank, used, float((Y - exp).norm() / exp.norm()), float(((Y - exp).abs() / scale.clamp_min(1e-30)).max())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("slices", [1, 2])
+def test_two_ranks_take_the_tile_group_kernel_on_a_dense_enough_graph(gpu_device, slices):
+    """40 000 nodes, average degree ~300: each rank's 20 000 rows pass the sharing test, so the
+    rank-local multiply is the matrix-core kernel on the gathered (pre-scaled) operand."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tg_worker, args=(k, world, port, 40_000, 6_000_000, 200, 2, slices, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, used, normwise, elementwise in got:
+        assert used, "the tile-group plan was not built"
+        assert normwise <= 1e-5 and elementwise <= 1e-5
 
 
 def _nccl_single(port, q):
