@@ -400,6 +400,7 @@ def main():
                             0 if row_world == 1 else
                             (padj.max_rows * row_world if padj.halo is None else padj.halo["n_recv"])
                             * ((f1 - f0 + 3) // 4 * 4) * 4}
+                info["_padj"] = padj
                 out.append(((lambda sl=sl: padj.propagate(Xl, args.order, slices=sl)), info))
             return out
 
@@ -441,6 +442,7 @@ def main():
             torch.cuda.empty_cache()
         del row, col, X
         nnz, max_deg = info.pop("nnz"), info.pop("max_deg")
+        local = info.pop("_padj").local            # which kernel the rank-local multiply took (decided on first use)
         extra.update(info)
         extra["collective"] = (f"{info['exchange']} among {info['exchange_ranks']} ranks, backend "
                                f"{dist.get_backend()} ({'gloo rehearsal on one GPU' if rehearsal else 'RCCL'}), "
@@ -450,10 +452,15 @@ def main():
         if len(probed) > 1:
             extra["grid_probe_ms"] = probed
         lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
-        R = lib.sgnn_rowgroup_config(F)
-        kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
-        kernels_in_step = "k_row_scale + all-gather + " + ("k_rg_spmm + k_rg_combine" if R else "k_spmm")
-        main_kernel = "k_rg_spmm" if R else "k_spmm"
+        R = lib.sgnn_rowgroup_config(extra["features_per_rank"])
+        if getattr(local, "_tg", None):
+            kernel_path = "tile-group SpMM on the rank's rows (each rank splits the gathered operand)"
+            kernels_in_step = "k_row_scale + exchange + k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine"
+            main_kernel = "k_tg_spmm"
+        else:
+            kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
+            kernels_in_step = "k_row_scale + exchange + " + ("k_rg_spmm + k_rg_combine" if R else "k_spmm")
+            main_kernel = "k_rg_spmm" if R else "k_spmm"
 
     wall, ev_ms, k_ms, k_n = timed_steps(step, args.steps, args.warmup, device, world, dist if world > 1 else None)
 
@@ -497,7 +504,12 @@ def main():
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         units = nnz * F * args.order                          # (E + n) . F per hop
-        b_alg = algorithmic_bytes(n, nnz, F)                   # per launch of the main kernel (one hop)
+        if world == 1:
+            b_alg = algorithmic_bytes(n, nnz, F)               # per launch of the main kernel (one hop)
+        else:
+            # one rank's launch: its share of the CSR and of Y, its slice of the whole (gathered) X
+            rr, fr = extra["row_ranks"], extra["features_per_rank"]
+            b_alg = nnz // rr * 8 + (n // rr + 1) * 4 + 2 * (n // rr) * 4 + n * fr * 4 + (n // rr) * fr * 4
         launches_per_step = (k_n / args.steps) if k_n else args.order
         kernel_ms = k_ms if k_ms else ev_ms / launches_per_step
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
@@ -544,9 +556,10 @@ def main():
                 "kernel_ms": kernel_ms,                       # HIP events around every launch of the main kernel
                 "kernel_launches_timed": k_n,
                 "step_ms": ev_ms,                             # HIP events around the K steps / K: all kernels of a step
-                "frac_whole_step": b_alg * args.order / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_whole_step": b_alg * args.order / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,   # N > 1: exchange included
                 "kernels_in_step": kernels_in_step,
                 "gather_bytes_no_reuse": nnz * F * 4,
+                **({} if world == 1 else {"scope": "one rank's launch of the main kernel"}),
             },
         }
         roof = out["roofline"]
