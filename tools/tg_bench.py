@@ -40,7 +40,7 @@ adj.use_tilegroup = True
 t0 = time.perf_counter()
 Y_tg = adj.propagate(X, 1)
 torch.cuda.synchronize()
-print(f"{wl}: n={n} nnz={adj.nnz} F={F}; tile-group plan {adj._tg and {k: v for k, v in adj._tg.items() if k != 'buf'}} "
+print(f"{wl}: n={n} nnz={adj.nnz} F={F}; tile-group plan {adj._tg and {k: v for k, v in adj._tg.items() if k not in ('buf', 'bufs')}} "
       f"plan MB {adj._tg['bytes'] / 1e6:.0f}; first call {time.perf_counter() - t0:.2f} s; "
       f"flag {int(adj._tg_bufs[F]['state'][1].item())} tiny {int(adj._tg_bufs[F]['state'][4].item())}", flush=True)
 t_tg = timeit(lambda: adj.propagate(X, 1))
