@@ -208,7 +208,7 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           from the same, untouched workspace
  * Per operand:
  *   sgnn_tilegroup_split_f32  planes <- fp16 hi / lo of (scale_row[i] * X[i, :]) (scale_row
- *                           nullable; utils.py:93 when it is dinv); `state` is 16 bytes of
+ *                           nullable; utils.py:93 when it is dinv); `state` is 32 bytes of
  *                           device memory that carries the scale and the fall-back flag to
  *                           the SpMM call that follows on the same stream
  *   sgnn_spmm_tilegroup_f32   Y = diag(dinv_row) . (w_off * pattern + diag(corr)) . planes,

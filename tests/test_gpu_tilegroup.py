@@ -130,3 +130,27 @@ def test_tilegroup_hub_graph_with_split_groups(gpu_device, weight):
     scale = adj.propagate(X.abs(), 1)
     assert float((Y - Y_ref).norm() / Y_ref.norm()) <= TOL
     assert float(((Y - Y_ref).abs() / scale.clamp_min(1e-30)).max()) <= TOL
+
+
+def test_kernel_timer_counts_the_main_kernel_of_every_path(gpu_device):
+    """sgnn_kernel_time_ms: one timed launch per hop whichever kernel runs, nothing while switched off."""
+    from sgnn_amd import _lib
+    lib = _lib.load()
+    adj, r, c, v = _graph(3000, 40_000, seed=21, dev=gpu_device)
+    X = torch.randn(3000, 128, device=gpu_device)
+    adj.propagate(X, 1)                                   # plans built outside the count
+    assert _lib.kernel_time_ms() == (0.0, 0)
+    lib.sgnn_tune_set(b"time_kernel", 1)
+    try:
+        adj.propagate(X, 2)                               # tile-group: two hops
+        adj.use_tilegroup = False
+        adj.propagate(X, 1)                               # row-group
+        adj.use_rowgroup = False
+        adj.propagate(X, 3)                               # plain CSR chain: three hops
+        total, launches = _lib.kernel_time_ms()
+        assert launches == 6 and 0.0 < total < 1000.0
+        assert _lib.kernel_time_ms() == (0.0, 0)          # reading starts a new count
+    finally:
+        lib.sgnn_tune_set(b"time_kernel", 0)
+    adj.propagate(X, 1)
+    assert _lib.kernel_time_ms() == (0.0, 0)
