@@ -66,8 +66,8 @@ constexpr int kBitsBytes = kMaxStageSteps * 64;
 constexpr int kHdrBytes = 512;                   // first steps of this stage's and the next stages' sub-tiles
 constexpr int kColsBytes = 1024;                 // column ids of the next two stages
 constexpr int kStageBytes = kStageRowsBytes + kSlotsBytes + kBitsBytes + kHdrBytes + kColsBytes;   // 79360 = 155 * 512
-constexpr int kTableBytes = 512;                 // pattern table at LDS offset 0; the stage buffers follow, 512-byte aligned
-constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;
+constexpr int kTableBytes = 4096;                // pattern table at LDS offset 0 (256 entries of 16 bytes); the stage buffers follow
+constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;   // 162816 of the CU's 163840
 constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slack behind the step arrays (a stage's DMA over-reads)
 static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wavefront loads 16 rows of a stage");
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
@@ -381,7 +381,9 @@ __global__ void k_tg_fill_steps(int64_t nnz, const uint64_t* __restrict__ keys2,
   }
   const int64_t step = int64_t(step0[run]) + j / kStepCols;
   const uint32_t kpos = j % kStepCols;
-  if (head[i]) step_slots[step * 16 + kpos] = uint16_t((slot >> 2) * (4 * kRowBytes) + ((slot & 3u) << 6));
+  // stored so that the two offsets one lane of the kernel needs (columns 8 h + q and 8 h + 4 + q) share a dword
+  const uint32_t spos = 2u * (4u * (kpos >> 3) + (kpos & 3u)) + ((kpos >> 2) & 1u);
+  if (head[i]) step_slots[step * 16 + spos] = uint16_t((slot >> 2) * (4 * kRowBytes) + ((slot & 3u) << 6));
   atomicOr(&step_bits32[step * 16 + (r5 >> 1)], 1u << (kpos + 16u * (r5 & 1u)));
 }
 
@@ -633,17 +635,16 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   constexpr uint32_t lds0 = 0;   // LDS address of smem: the dynamic segment follows the static one, and there is none
   const char* xs = a.planes + int64_t(slice) * a.slice_bytes;
 
-  // Pattern table at LDS offset 0: entry v (a nibble of row bits) holds two dwords of fp16
-  // pairs with 1.0 where the bit is set (hi plane), then the same with 2^-11 (lo plane, which
-  // holds the remainder times 2048).
-  uint32_t* tbl = reinterpret_cast<uint32_t*>(smem);
-  if (tid < 16) {
-    const uint32_t d0 = ((tid & 1) ? 0x3C00u : 0u) | ((tid & 2) ? 0x3C000000u : 0u);
-    const uint32_t d1 = ((tid & 4) ? 0x3C00u : 0u) | ((tid & 8) ? 0x3C000000u : 0u);
-    tbl[4 * tid] = d0;
-    tbl[4 * tid + 1] = d1;
-    tbl[4 * tid + 2] = d0 & 0x10001000u;
-    tbl[4 * tid + 3] = d1 & 0x10001000u;
+  // Pattern table at LDS offset 0: entry v (the 8 column bits of a row) holds the row's hi-plane
+  // A operand, 8 fp16 values that are 1.0 where the bit is set; the lo-plane operand (2^-11,
+  // the lo plane holds the remainder times 2048) is the same with one bit of each half kept.
+  // One 16-byte read per step: the LDS array, busy throughout the step phase, is what bounds it.
+  if (tid < 256) {
+    uint32_t d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      d[i] = ((tid >> (2 * i)) & 1 ? 0x3C00u : 0u) | ((tid >> (2 * i + 1)) & 1 ? 0x3C000000u : 0u);
+    *reinterpret_cast<u32x4*>(smem + 16 * tid) = u32x4{d[0], d[1], d[2], d[3]};
   }
 
   f32x16 acc[2][NT];
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   // of columns 16 g1 + 4 p .. + 3 of the row whose k index is 8 h + 4 r + q (read r = 0, 1)
   const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
   const uint32_t lane_off = uint32_t(32 * g1 + 8 * p);
-  const uint32_t offs_off = uint32_t(kStageRowsBytes + 2 * (8 * h + q));   // this lane's entry of a step's offsets (r = 0)
+  const uint32_t offs_off = uint32_t(kStageRowsBytes + 4 * (4 * h + q));   // this lane's dword of a step's offsets (r = 0 | r = 1 << 16)
   const uint32_t bits_off = uint32_t(kStageRowsBytes + kSlotsBytes + 2 * (lane & 31) + h);
   // A row of a stage is 512 bytes: eight 64-byte segments, hi N-tiles 0..3 then lo N-tiles 0..3.
   // The rows of slots 4 b .. 4 b + 3 form a 2 KB block of LDS, stored segment-major: segment s
@@ -757,28 +758,15 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     // the transposed reads, and its 8 row bits.  Reading past the wavefront's last record is
     // harmless (the bytes are inside the stage buffer, what is read is not used).
     uint32_t rec_o = boff + offs_off + uint32_t(b0) * 32u, rec_b = boff + bits_off + uint32_t(b0) * 64u;
-    auto record = [&](uint32_t& off_a, uint32_t& off_b, uint32_t& bt) {
-      off_a = *lds<const uint16_t>(rec_o);
-      off_b = *lds<const uint16_t>(rec_o + 8);
+    auto record = [&](uint32_t& offs, uint32_t& bt) {   // (loads only: the values are taken apart a step later)
+      offs = *lds<const uint32_t>(rec_o);
       bt = *lds<const uint8_t>(rec_b);
       rec_o += 32;
       rec_b += 64;
     };
-    // pattern tile of the lane's row from its 8 column bits: fp16 1.0 (hi plane) / 2^-11 (lo plane)
-    // where the bit of column k = 8 h + i is set; two table entries (one per nibble), each
-    // {hi pair, lo pair}
-    auto pattern_addr = [&](uint32_t bt, uint32_t& ta, uint32_t& tb) {
-      ta = (bt & 15u) << 4;
-      tb = bt & 0xF0u;
-    };
-    auto pattern_hi = [&](uint32_t ta, uint32_t tb) {
-      const u32x2 x = *lds<const u32x2>(ta), y = *lds<const u32x2>(tb);
-      return u32x4{x[0], x[1], y[0], y[1]};
-    };
-    auto pattern_lo = [&](uint32_t ta, uint32_t tb) {
-      const u32x2 x = *lds<const u32x2>(ta + 8), y = *lds<const u32x2>(tb + 8);
-      return u32x4{x[0], x[1], y[0], y[1]};
-    };
+    // pattern tile of the lane's row from its 8 column bits: one table entry
+    auto pattern_hi = [&](uint32_t bt) { return *lds<const u32x4>(bt << 4); };
+    auto pattern_lo = [&](const u32x4& hi) { return hi & 0x10001000u; };
     auto read_tile = [&](uint32_t base_a, uint32_t base_b, int seg) {   // seg: 0..3 = hi N-tiles, 4..7 = lo
       const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_a + uint32_t(seg * 256)));
       const hv4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_b + uint32_t(seg * 256)));
@@ -801,33 +789,32 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     if (total > 0 && !(a.mode & 1)) {
       u32x4 ahi, alo;                             // pattern tiles of the current step
       uint32_t base_a, base_b;                    // row addresses of the step whose tiles are being read
-      uint32_t off_a, off_b, bt;                  // record of the step after that
-      uint32_t ta, tb;
+      uint32_t offs, bt;                          // record of the step after that: both row offsets, row bits
+      uint32_t btn;
       h8 bh[NT], bl[NT];
-      record(off_a, off_b, bt);
-      pattern_addr(bt, ta, tb);
-      ahi = pattern_hi(ta, tb);
-      alo = pattern_lo(ta, tb);
-      base_a = stage_lane + off_a;
-      base_b = stage_lane + off_b;
+      record(offs, bt);
+      ahi = pattern_hi(bt);
+      alo = pattern_lo(ahi);
+      base_a = stage_lane + (offs & 0xFFFFu);
+      base_b = stage_lane + (offs >> 16);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, nt);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, NT + nt);
-      record(off_a, off_b, bt);
+      record(offs, bt);
       auto body = [&](auto tt_tag) {
         constexpr int TT = decltype(tt_tag)::value;
-        base_a = stage_lane + off_a;
-        base_b = stage_lane + off_b;
-        pattern_addr(bt, ta, tb);
-        record(off_a, off_b, bt);
+        base_a = stage_lane + (offs & 0xFFFFu);
+        base_b = stage_lane + (offs >> 16);
+        btn = bt << 4;
+        record(offs, bt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), bh[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           bh[nt] = read_tile(base_a, base_b, nt);
-          if (nt == NT - 1) ahi = pattern_hi(ta, tb);
+          if (nt == NT - 1) ahi = *lds<const u32x4>(btn);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -835,7 +822,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
           acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), bl[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           bl[nt] = read_tile(base_a, base_b, NT + nt);
-          if (nt == NT - 1) alo = pattern_lo(ta, tb);
+          if (nt == NT - 1) alo = pattern_lo(ahi);
           __builtin_amdgcn_sched_barrier(0);
         }
       };

@@ -13,7 +13,8 @@ import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); seen = set()
 for r in csv.DictReader(open(f)):
-    k = r["Kernel_Name"].split("(")[0][-40:]
+    n = r["Kernel_Name"]
+    k = next((t for t in ("k_tg_spmm", "k_rg_spmm", "k_spmm", "k_tg_split", "k_tg_combine") if t in n), n[:40])
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     key = (k, r["Dispatch_Id"])
     if key not in seen:
