@@ -66,8 +66,8 @@ constexpr int kBitsBytes = kMaxStageSteps * 64;
 constexpr int kHdrBytes = 512;                   // first steps of this stage's and the next stages' sub-tiles
 constexpr int kColsBytes = 1024;                 // column ids of the next two stages
 constexpr int kStageBytes = kStageRowsBytes + kSlotsBytes + kBitsBytes + kHdrBytes + kColsBytes;   // 79360 = 155 * 512
-constexpr int kTableBytes = 4096;                // pattern table at LDS offset 0 (256 entries of 16 bytes); the stage buffers follow
-constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;   // 162816 of the CU's 163840
+constexpr int kTableBytes = 512;                 // pattern table at LDS offset 0 (16 entries of 8 bytes, the rest unused); the stage buffers follow
+constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;
 constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slack behind the step arrays (a stage's DMA over-reads)
 static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wavefront loads 16 rows of a stage");
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
@@ -635,16 +635,16 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   constexpr uint32_t lds0 = 0;   // LDS address of smem: the dynamic segment follows the static one, and there is none
   const char* xs = a.planes + int64_t(slice) * a.slice_bytes;
 
-  // Pattern table at LDS offset 0: entry v (the 8 column bits of a row) holds the row's hi-plane
-  // A operand, 8 fp16 values that are 1.0 where the bit is set; the lo-plane operand (2^-11,
-  // the lo plane holds the remainder times 2048) is the same with one bit of each half kept.
-  // One 16-byte read per step: the LDS array, busy throughout the step phase, is what bounds it.
-  if (tid < 256) {
-    uint32_t d[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      d[i] = ((tid >> (2 * i)) & 1 ? 0x3C00u : 0u) | ((tid >> (2 * i + 1)) & 1 ? 0x3C000000u : 0u);
-    *reinterpret_cast<u32x4*>(smem + 16 * tid) = u32x4{d[0], d[1], d[2], d[3]};
+  // Pattern table at LDS offset 0: entry v (a nibble of a row's column bits) holds two dwords of
+  // fp16 pairs with 1.0 where the bit is set: half of the row's hi-plane A operand.  The
+  // lo-plane operand (2^-11: the lo plane holds the remainder times 2048) is the same with one
+  // bit of each half kept.  Lanes with equal nibbles read one address, lanes with different
+  // nibbles different banks: no conflicts (a 256-entry table read in one go had them, and the
+  // LDS array, busy throughout the step phase, is what bounds the loop).
+  if (tid < 16) {
+    const uint32_t d0 = ((tid & 1) ? 0x3C00u : 0u) | ((tid & 2) ? 0x3C000000u : 0u);
+    const uint32_t d1 = ((tid & 4) ? 0x3C00u : 0u) | ((tid & 8) ? 0x3C000000u : 0u);
+    *reinterpret_cast<u32x2*>(smem + 8 * tid) = u32x2{d0, d1};
   }
 
   f32x16 acc[2][NT];
@@ -764,8 +764,11 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
       rec_o += 32;
       rec_b += 64;
     };
-    // pattern tile of the lane's row from its 8 column bits: one table entry
-    auto pattern_hi = [&](uint32_t bt) { return *lds<const u32x4>(bt << 4); };
+    // pattern tile of the lane's row from its 8 column bits: one table entry per nibble
+    auto pattern_hi = [&](uint32_t ta, uint32_t tb) {
+      const u32x2 x = *lds<const u32x2>(ta), y = *lds<const u32x2>(tb);
+      return u32x4{x[0], x[1], y[0], y[1]};
+    };
     auto pattern_lo = [&](const u32x4& hi) { return hi & 0x10001000u; };
     auto read_tile = [&](uint32_t base_a, uint32_t base_b, int seg) {   // seg: 0..3 = hi N-tiles, 4..7 = lo
       const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_a + uint32_t(seg * 256)));
@@ -790,10 +793,10 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
       u32x4 ahi, alo;                             // pattern tiles of the current step
       uint32_t base_a, base_b;                    // row addresses of the step whose tiles are being read
       uint32_t offs, bt;                          // record of the step after that: both row offsets, row bits
-      uint32_t btn;
+      uint32_t ta, tb;
       h8 bh[NT], bl[NT];
       record(offs, bt);
-      ahi = pattern_hi(bt);
+      ahi = pattern_hi((bt & 15u) << 3, (bt >> 1) & 0x78u);
       alo = pattern_lo(ahi);
       base_a = stage_lane + (offs & 0xFFFFu);
       base_b = stage_lane + (offs >> 16);
@@ -806,7 +809,8 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
         constexpr int TT = decltype(tt_tag)::value;
         base_a = stage_lane + (offs & 0xFFFFu);
         base_b = stage_lane + (offs >> 16);
-        btn = bt << 4;
+        ta = (bt & 15u) << 3;
+        tb = (bt >> 1) & 0x78u;
         record(offs, bt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
           acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), bh[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           bh[nt] = read_tile(base_a, base_b, nt);
-          if (nt == NT - 1) ahi = *lds<const u32x4>(btn);
+          if (nt == NT - 1) ahi = pattern_hi(ta, tb);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
