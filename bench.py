@@ -56,7 +56,7 @@ def kernel_of(adj, F):
         return ("tile-group SpMM (512-row groups share fetched rows through LDS; fp16 hi/lo planes of X on "
                 "v_mfma_f32_32x32x16_f16, fp32 accumulation)", "k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine",
                 "k_tg_spmm")
-    R = lib.sgnn_rowgroup_config(F) if adj.use_rowgroup else 0
+    R = lib.sgnn_rowgroup_config_for(adj.n, adj.nnz, F) if adj.use_rowgroup else 0
     if R:
         return f"row-group SpMM, R={R}", "k_row_scale + k_rg_spmm + k_rg_combine", "k_rg_spmm"
     return "plain CSR SpMM", "k_spmm + k_spmm_combine", "k_spmm"
@@ -452,7 +452,7 @@ def main():
         if len(probed) > 1:
             extra["grid_probe_ms"] = probed
         lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
-        R = lib.sgnn_rowgroup_config(extra["features_per_rank"])
+        R = lib.sgnn_rowgroup_config_for(local.n_rows, local.adj.nnz, extra["features_per_rank"])
         if getattr(local, "_tg", None):
             kernel_path = "tile-group SpMM on the rank's rows (each rank splits the gathered operand)"
             kernels_in_step = "k_row_scale + exchange + k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine"

@@ -259,6 +259,10 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
  *
  * sgnn_rowgroup_config   R to build the plan with for feature width F
  *                        (0: this F is not supported, use sgnn_spmm_csr_f32)
+ * sgnn_rowgroup_config_for  the same choice made with the graph's size known: a graph
+ *                        with n_rows / 16 + nnz / 64 < 8192 takes R = 8 at every supported
+ *                        width (too few work items at R = 16 to occupy the chip); either
+ *                        R is valid for every supported F
  * sgnn_rowgroup_build    fills `plan` (device, sgnn_rowgroup_plan_bytes) from the
  *                        CSR; when the stream has drained, the first four int64
  *                        of `plan` hold {merged entries, launch slots, partial
@@ -294,6 +298,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
  * COO tensor (utils.py:54-62).
  */
 int sgnn_rowgroup_config(int64_t F);
+int sgnn_rowgroup_config_for(int64_t n_rows, int64_t nnz, int64_t F);
 size_t sgnn_rowgroup_plan_bytes(int64_t n_rows, int64_t nnz, int R);
 size_t sgnn_rowgroup_workspace_bytes(int64_t n_rows, int64_t nnz, int R);
 int sgnn_rowgroup_build(int64_t n_rows, int64_t n_cols, int64_t nnz,

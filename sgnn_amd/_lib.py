@@ -46,6 +46,7 @@ SIGNATURES = {
     "sgnn_spmm_chain_f32": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sgnn_rowgroup_config": (c_int, [c_int64]),
+    "sgnn_rowgroup_config_for": (c_int, [c_int64, c_int64, c_int64]),
     "sgnn_rowgroup_plan_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "sgnn_rowgroup_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "sgnn_rowgroup_build": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t,

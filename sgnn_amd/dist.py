@@ -417,7 +417,7 @@ class _LocalBlock:
         if a.nnz == 0:
             return None
         lib = _lib.load()
-        R = lib.sgnn_rowgroup_config(F)
+        R = lib.sgnn_rowgroup_config_for(self.n_rows, a.nnz, F)
         if R == 0:
             return None
         plan = self._plans.get(R)

@@ -267,7 +267,7 @@ class NormAdj:
         if not self.use_rowgroup or self.nnz == 0:
             return None
         lib = _lib.load()
-        R = lib.sgnn_rowgroup_config(F)
+        R = lib.sgnn_rowgroup_config_for(self.n, self.nnz, F)
         if R == 0:
             return None
         plan = self._plans.get(R)

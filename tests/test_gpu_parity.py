@@ -284,16 +284,23 @@ def test_unit_weight_graph_rowgroup_and_plain_kernels(dev, F, order):
     for _ in range(order):
         exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, exp)
     Xd = torch.from_numpy(X).to(dev)
-    supported = _lib.load().sgnn_rowgroup_config(F) != 0
-    for flag in (True, False):
-        adj.use_rowgroup = flag
-        Y = adj.propagate(Xd, order)
-        _check_Y(Y, exp, rowptr, colidx, vals, dinv, X, order)
-        assert torch.equal(Y, adj.propagate(Xd, order))
-        assert (adj._rowgroup_plan(F) is not None) == (flag and supported)
-    if supported:
-        plan = adj._rowgroup_plan.__self__._plans[_lib.load().sgnn_rowgroup_config(F)]
-        assert 0 < plan["merged"] <= adj.nnz and plan["n_long"] >= 1     # hubs: split groups exercised
+    lib = _lib.load()
+    supported = lib.sgnn_rowgroup_config(F) != 0
+    try:
+        # both group sizes (a graph this small takes 8 by default), then the plain kernel
+        for flag, rows in ((True, 0), (True, 16), (True, 8), (False, 0)):
+            lib.sgnn_tune_set(b"rg_R", rows)
+            adj.use_rowgroup = flag
+            Y = adj.propagate(Xd, order)
+            _check_Y(Y, exp, rowptr, colidx, vals, dinv, X, order)
+            assert torch.equal(Y, adj.propagate(Xd, order))
+            plan = adj._rowgroup_plan(F)
+            assert (plan is not None) == (flag and supported)
+            if plan is not None:
+                assert plan["R"] == (rows or 8)
+                assert 0 < plan["merged"] <= adj.nnz and plan["n_long"] >= 1     # hubs: split groups exercised
+    finally:
+        lib.sgnn_tune_set(b"rg_R", 0)
 
 
 def test_strided_input_and_order_zero(dev):

@@ -77,6 +77,11 @@ def test_argument_errors_are_reported_not_crashes():
     assert lib.sgnn_rowgroup_weights(4, 4, None, None, None, 16, None, 0, 4, None, 0, None) == -1
     assert lib.sgnn_rowgroup_config(16) == 0 and lib.sgnn_rowgroup_config(64) == 8
     assert lib.sgnn_rowgroup_config(602) == 16 and lib.sgnn_rowgroup_config(3703) == 16
+    # few rows: not enough groups of 16 to occupy the chip
+    assert lib.sgnn_rowgroup_config_for(19717, 108395, 500) == 8
+    assert lib.sgnn_rowgroup_config_for(232965, 114848857, 602) == 16
+    assert lib.sgnn_rowgroup_config_for(29121, 14356107, 602) == 16          # few rows, many entries
+    assert lib.sgnn_rowgroup_config_for(19717, 108395, 16) == 0 and lib.sgnn_rowgroup_config_for(232965, 10 ** 8, 64) == 8
 
 
 def test_no_cpu_fallback():

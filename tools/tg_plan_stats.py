@@ -26,7 +26,10 @@ per = (step0[1:] - step0[:-1]).view(stages, 16)                     # steps of (
 print("steps per (stage, sub-tile): mean %.2f" % per.float().mean().item(), "hist", torch.bincount(per.flatten(), minlength=9).tolist())
 wave = per[:, :8] + per[:, 8:].flip(1)                               # wavefront w: sub-tiles w and 15 - w
 wave_old = per[:, :8] + per[:, 8:]
-for name, wv in (("w,15-w", wave), ("w,w+8", wave_old)):
+wave_now = per[:, 0::2] + per[:, 1::2]                               # what the kernel does: sub-tiles 2 w and 2 w + 1
+srt = per.sort(1).values
+wave_best = srt[:, :8] + srt[:, 8:].flip(1)                          # per stage: largest with smallest (needs free ownership)
+for name, wv in (("2w,2w+1 (kernel)", wave_now), ("w,15-w", wave), ("w,w+8", wave_old), ("sorted per stage", wave_best)):
     mx, mean = wv.max(1).values.float(), wv.float().mean(1)
     print(f"{name}: steps per wavefront and stage mean {mean.mean():.2f}; sum of max over stages {mx.sum():.0f} "
           f"vs sum of mean {mean.sum():.0f}: imbalance {mx.sum() / mean.sum():.3f}")
