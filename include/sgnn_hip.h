@@ -274,10 +274,14 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
  *                        equal length, so the count can exceed the item count.
  * sgnn_spmm_rowgroup_f32 workspace >= sgnn_spmm_rowgroup_workspace_bytes(slots, R, F).
  *                        X must already carry the column scaling of utils.py:93
- *                        (sgnn_row_scale_f32; dinv_col must be NULL) and its rows must
+ *                        (sgnn_row_scale_f32; dinv_col NULL) and its rows must
  *                        start on 16-byte boundaries (X 16-byte aligned, ldx % 4 == 0):
  *                        the kernel reads them with 16-byte loads; SGNN_ERR_UNSUPPORTED
- *                        otherwise, and for F < 33.  Widths above 640 run as equal
+ *                        otherwise, and for F < 33.  With R = 8, no group weights and X
+ *                        below 4 GiB, dinv_col may be given instead: the kernel then scales
+ *                        every fetched row itself (one launch and one pass over X less,
+ *                        which is what a graph that fits the caches is bound by; larger
+ *                        graphs are faster with X scaled once up front).  Widths above 640 run as equal
  *                        feature slices of at most 640 columns, one launch each.
  *                        The plan stores the sparsity pattern only.  An adjacency whose
  *                        off-diagonal entries all carry one weight w_off (Reddit's A + A^T

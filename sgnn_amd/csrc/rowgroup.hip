@@ -381,6 +381,7 @@ struct RgArgs {
   const uint32_t* gmask;
   const int32_t *item_group, *item_m0, *item_m1, *item_out, *long_group, *long_slot;
   const float *dinv_row, *X, *corr;
+  const float* dinv_col;   // scale of every fetched row (utils.py:93) applied in the kernel; NULL: X arrives scaled
   const float* gw;   // [merged][R] weight of (merged column, row of the group), NULL: pattern only
   float *Y, *partial;
   int64_t ldx, ldy, x_bytes, x_row_offset;
@@ -415,14 +416,18 @@ __device__ __forceinline__ int rg_voff(const RgArgs& a, int c, int chunks, int f
   return feature * 4;
 }
 
+// Weight modes of the kernel: pattern sum (the fetched rows are added as they are), one
+// weight per (merged column, row of the group) pair, one scale per fetched row.
+constexpr int kPattern = 0, kPairWeights = 1, kColScale = 2;
+
 // Issue the fetches of UU consecutive merged columns (lanes k .. k+UU-1 of `cols`).
-// With weights (HASW) the R weights of each of the UU columns follow: they are stored
+// With pair weights the R weights of each of the UU columns follow: they are stored
 // [merged column][row of the group], so one coalesced load by the first UU*R lanes brings
 // the whole step's weights (`mabs` = index of the step's first column in the merged list).
-template <class L, int R, int C4, int C2, int C1, int UU, bool BIGX, bool HASW>
+template <class L, int R, int C4, int C2, int C1, int UU, bool BIGX, int WM>
 __device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t cols, int k, int lane, int64_t mabs,
                                         float (&xv)[UU][L::NF], float& wv) {
-  if constexpr (HASW) {
+  if constexpr (WM == kPairWeights) {
     static_assert(UU * R <= kWave, "a step's weights must fit one wavefront-wide load");
     wv = lane < UU * R ? a.gw[mabs * R + lane] : 0.0f;
   }
@@ -461,22 +466,36 @@ __device__ __forceinline__ void rg_load(const RgArgs& a, i32x4 rsrc, int32_t col
 // indexed accumulator was tried: the compiler folds the tree's leaves into one
 // dynamically indexed access and moves the accumulators to scratch memory; with the
 // fold blocked the kernel needs 386 registers, one wavefront per SIMD.)
-template <int R, int NF, int UU, bool HASW>
-__device__ __forceinline__ void rg_accum(uint32_t masks, int k, const float (&xv)[UU][NF], float wv,
+// (`wv`: the step's pair weights as rg_load left them; `dc`: the scales of the batch's 64
+// columns, one per lane.)
+template <int R, int NF, int UU, int WM>
+__device__ __forceinline__ void rg_accum(uint32_t masks, int k, const float (&xv)[UU][NF], float wv, float dc,
                                          float (&acc)[R][NF]) {
 #pragma unroll
   for (int u = 0; u < UU; ++u) {
     const uint32_t mk = uint32_t(__builtin_amdgcn_readlane(int(masks), k + u));
+    // Column scale: the fetched row is scaled once, rounded, and then added like a row that
+    // arrived scaled, so that the result does not depend on who applied the scaling.
+    [[maybe_unused]] float xs[NF];
+    if constexpr (WM == kColScale) {
+#pragma clang fp contract(off)
+      const float wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dc), k + u));
+#pragma unroll
+      for (int i = 0; i < NF; ++i) xs[i] = wc * xv[u][i];
+    }
 #pragma unroll
     for (int q = 0; q < R; q += 4)
       if (mk & (0xFu << q)) {   // wave-uniform: scalar tests and branches throughout
 #pragma unroll
         for (int r = q; r < q + 4; ++r)
           if (mk & (1u << r)) {
-            if constexpr (HASW) {
+            if constexpr (WM == kPairWeights) {
               const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), u * R + r));
 #pragma unroll
               for (int i = 0; i < NF; ++i) acc[r][i] = fmaf(w, xv[u][i], acc[r][i]);
+            } else if constexpr (WM == kColScale) {
+#pragma unroll
+              for (int i = 0; i < NF; ++i) acc[r][i] += xs[i];
             } else {
 #pragma unroll
               for (int i = 0; i < NF; ++i) acc[r][i] += xv[u][i];
@@ -497,7 +516,9 @@ __device__ __forceinline__ float rg_epilogue(const RgArgs& a, float s, int row, 
     // the weights were applied entry by entry
   } else if (a.corr != nullptr) {
     const int64_t xr = int64_t(row) + a.x_row_offset;
-    y = fmaf(a.w_off, y, a.corr[row] * a.X[xr * a.ldx + f]);
+    float xs = a.X[xr * a.ldx + f];
+    if (a.dinv_col != nullptr) xs *= a.dinv_col[xr];
+    y = fmaf(a.w_off, y, a.corr[row] * xs);
   } else if (a.w_off != 1.0f) {
     y *= a.w_off;
   }
@@ -581,7 +602,7 @@ __device__ __forceinline__ void rg_write_rows(const RgArgs& a, const float (&acc
 // Merged columns are taken 64 at a time through a VGPR (ids and masks) and handed to
 // the scalar unit by v_readlane; every row of a group is summed in ascending column
 // order.
-template <int R, int C4, int C2, int C1, int U, bool BIGX, bool HASW>
+template <int R, int C4, int C2, int C1, int U, bool BIGX, int WM>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
   using L = Lay<C4, C2, C1>;
   constexpr int NF = L::NF;
@@ -603,9 +624,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
 
   int32_t ncols = 0;
   uint32_t nmask = 0;
+  float ndc = 0.0f;   // column-scale mode: the scales of the batch's columns
   if (m0 + lane < m1) {
     ncols = a.gcol[m0 + lane];
     nmask = a.gmask[m0 + lane];
+    if constexpr (WM == kColScale) ndc = a.dinv_col[ncols];
   }
   // Two fetch buffers: while the rows of one step are added, the fetches of the
   // following step are already in flight (also across the 64-column batches).
@@ -614,10 +637,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
   // so an odd number of full steps can only occur in the last batch.
   float xa[U][NF], xb[U][NF];
   float wa = 0.0f, wb = 0.0f;
-  if (min(kWave, m1 - m0) >= U) rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, ncols, 0, lane, m0, xa, wa);
+  if (min(kWave, m1 - m0) >= U) rg_load<L, R, C4, C2, C1, U, BIGX, WM>(a, rsrc, ncols, 0, lane, m0, xa, wa);
   for (int m = m0; m < m1; m += kWave) {
     const int32_t cols = ncols;
     const uint32_t masks = nmask;
+    const float dc = ndc;
     const int cnt = min(kWave, m1 - m);
     const bool more = m + kWave < m1;
     const bool mine = m + kWave + lane < m1;
@@ -629,22 +653,25 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_rg_spmm(RgArgs a) {
     const bool next_full_step = more && (m1 - (m + kWave)) >= U;
     int k = 0;
     for (; k + 2 * U <= nfull; k += 2 * U) {
-      rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, cols, k + U, lane, m + k + U, xb, wb);
-      rg_accum<R, NF, U, HASW>(masks, k, xa, wa, acc);
-      if (k + 2 * U < nfull) rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, cols, k + 2 * U, lane, m + k + 2 * U, xa, wa);
-      else if (next_full_step) rg_load<L, R, C4, C2, C1, U, BIGX, HASW>(a, rsrc, ncols, 0, lane, m + kWave, xa, wa);
-      rg_accum<R, NF, U, HASW>(masks, k + U, xb, wb, acc);
+      rg_load<L, R, C4, C2, C1, U, BIGX, WM>(a, rsrc, cols, k + U, lane, m + k + U, xb, wb);
+      rg_accum<R, NF, U, WM>(masks, k, xa, wa, dc, acc);
+      if (k + 2 * U < nfull) rg_load<L, R, C4, C2, C1, U, BIGX, WM>(a, rsrc, cols, k + 2 * U, lane, m + k + 2 * U, xa, wa);
+      else if (next_full_step) rg_load<L, R, C4, C2, C1, U, BIGX, WM>(a, rsrc, ncols, 0, lane, m + kWave, xa, wa);
+      rg_accum<R, NF, U, WM>(masks, k + U, xb, wb, dc, acc);
     }
     if (k < nfull) {   // odd count of full steps: last batch only, xa holds the step
-      rg_accum<R, NF, U, HASW>(masks, k, xa, wa, acc);
+      rg_accum<R, NF, U, WM>(masks, k, xa, wa, dc, acc);
       k += U;
     }
     for (; k < cnt; ++k) {
       float x1[1][NF];
       float w1 = 0.0f;
-      rg_load<L, R, C4, C2, C1, 1, BIGX, HASW>(a, rsrc, cols, k, lane, m + k, x1, w1);
-      rg_accum<R, NF, 1, HASW>(masks, k, x1, w1, acc);
+      rg_load<L, R, C4, C2, C1, 1, BIGX, WM>(a, rsrc, cols, k, lane, m + k, x1, w1);
+      rg_accum<R, NF, 1, WM>(masks, k, x1, w1, dc, acc);
     }
+    // the next batch's scales: its column ids were asked for at the top of this batch
+    if constexpr (WM == kColScale)
+      if (more) ndc = mine ? a.dinv_col[ncols] : 0.0f;
   }
   rg_write_rows<R, C4, C2, C1>(a, acc, g, out, lane);
 }
@@ -693,11 +720,15 @@ int launch_rg(const RgArgs& a, hipStream_t st) {
   const bool bigx = a.x_bytes >= kBigX;
   sgnn::kernel_timer_begin(st);
   if (a.gw != nullptr) {
-    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, true, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, false, true>), grid, block, 0, st, a);
+    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, true, kPairWeights>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, UW, false, kPairWeights>), grid, block, 0, st, a);
+  } else if (a.dinv_col != nullptr) {
+    // built for the groups of 8 of small graphs only (the entry point has checked R and the size of X)
+    if constexpr (R == 8) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, false, kColScale>), grid, block, 0, st, a);
+    else return fail(SGNN_ERR_UNSUPPORTED, "column scaling inside the row-group kernel needs R = 8");
   } else {
-    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, true, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, false, false>), grid, block, 0, st, a);
+    if (bigx) hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, true, kPattern>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_rg_spmm<R, C4, C2, C1, U, false, kPattern>), grid, block, 0, st, a);
   }
   HIP_TRY(hipGetLastError());
   sgnn::kernel_timer_end(st);
@@ -926,8 +957,14 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
     return fail(SGNN_ERR_INVALID, "X and Y must be 4-byte aligned");
   if (epilogue != SGNN_EPI_SCALE_ROW && epilogue != SGNN_EPI_SCALE_ROW2)
     return fail(SGNN_ERR_INVALID, "unknown epilogue mode");
-  if (dinv_col != nullptr)
-    return fail(SGNN_ERR_UNSUPPORTED, "the row-group kernel takes X already scaled by columns (sgnn_row_scale_f32)");
+  // Column scaling inside the kernel costs a gather and a multiply per fetched row that the
+  // large graphs do better without (they take X scaled once by sgnn_row_scale_f32); it is
+  // built for R = 8, pattern plans and X below 4 GiB, where it saves a small graph a launch
+  // and a pass over X.
+  if (dinv_col != nullptr && (R != 8 || group_weights != nullptr || ((n_cols - 1) * ldx + F) * 4 >= kBigX))
+    return fail(SGNN_ERR_UNSUPPORTED,
+                "column scaling inside the row-group kernel: only R = 8, no group weights, X below 4 GiB "
+                "(else scale X first: sgnn_row_scale_f32)");
   if (reinterpret_cast<uintptr_t>(X) % 16 || ldx % 4)
     return fail(SGNN_ERR_UNSUPPORTED, "the row-group kernel needs X 16-byte aligned with ldx a multiple of 4");
   if (F < 33) return fail(SGNN_ERR_UNSUPPORTED, "F too narrow for the row-group kernel");
@@ -943,6 +980,7 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
   a.long_group = p.long_group; a.long_slot = p.long_slot;
   a.dinv_row = dinv_row; a.partial = static_cast<float*>(workspace);
   a.gw = group_weights;
+  a.dinv_col = dinv_col;
   a.w_off = w_off; a.corr = corr; a.x_row_offset = x_row_offset;
   if (corr && (x_row_offset < 0 || x_row_offset + n_rows > n_cols))
     return fail(SGNN_ERR_INVALID, "x_row_offset places the block's own rows outside X");

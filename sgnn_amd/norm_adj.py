@@ -328,20 +328,30 @@ class NormAdj:
             plan["ws"] = {F: ws}
         return ws
 
+    def _folds_col_scale(self, plan, ldx):
+        """True when the row-group kernel applies the column scaling itself for this plan and
+        an operand of row stride ``ldx``: groups of 8 (what small graphs take) on a pattern
+        plan, X below 4 GiB.  It saves a launch and a pass over X; large graphs are faster
+        with X scaled once up front."""
+        return plan is not None and plan["R"] == 8 and plan["gw"] is None and self.n * ldx * 4 < 2 ** 32 - 8192
+
     def _hop(self, X, ldx, Y, ldy, F, scale_rows, scale_cols, epilogue):
         """Enqueue one SpMM launch sequence: the row-group kernel when a plan
         exists for this width, the plain CSR kernel otherwise."""
         lib = _lib.load()
         dinv = _lib.ptr(self.dinv)
         # the row-group kernel reads rows of X with 16-byte loads and takes X already scaled
+        # (plans of small graphs excepted)
         aligned = X.data_ptr() % 16 == 0 and ldx % 4 == 0
-        plan = self._rowgroup_plan(F) if (aligned and not scale_cols) else None
+        plan = self._rowgroup_plan(F) if aligned else None
+        if scale_cols and not self._folds_col_scale(plan, ldx):
+            plan = None
         if plan is not None:
             ws = self._rowgroup_ws(plan, F)
             _lib.check(lib.sgnn_spmm_rowgroup_f32(
                 self.n, self.n, self.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"], _lib.ptr(plan["gw"]),
                 plan["items"], plan["slots"], plan["n_long"],
-                dinv if scale_rows else None, None,
+                dinv if scale_rows else None, dinv if scale_cols else None,
                 float(self.w_off if self.w_off is not None else 1.0), _lib.ptr(self.corr), 0,
                 _lib.ptr(X), ldx, _lib.ptr(Y), ldy, int(epilogue), _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(self.device)))
@@ -381,7 +391,9 @@ class NormAdj:
             if tg is not None:
                 self._tilegroup_hop(tg, X, ldx, Y, Y.stride(0) if self.n > 1 else F, F, scale_rows, scale_cols, epilogue)
                 return Y
-            if self._rowgroup_plan(F) is not None and (scale_cols or X.data_ptr() % 16 or ldx % 4):
+            plan = self._rowgroup_plan(F)
+            aligned = X.data_ptr() % 16 == 0 and ldx % 4 == 0
+            if plan is not None and not (aligned and (not scale_cols or self._folds_col_scale(plan, ldx))):
                 # stage X for the row-group kernel: column scaling applied (utils.py:93),
                 # rows on 16-byte boundaries
                 X = self._staged(X, ldx, F, scale_cols)
@@ -444,16 +456,23 @@ class NormAdj:
             # The kernel reads rows with 16-byte loads, so the scaled copy and the
             # intermediates of a chain live in buffers whose row stride is a multiple of
             # 4 floats; only the last hop writes the caller-visible Y.
-            src = self._staged(X, X.stride(0) if X.shape[0] > 1 else F, F, True)
-            Fp = src.stride(0)
-            spare = torch.empty((self.n, Fp), dtype=torch.float32, device=self.device) if order > 1 else None
+            # A small graph's plan (groups of 8) scales the fetched rows inside the kernel on the
+            # first hop instead: one launch and one pass over X less, and X itself is read.
+            ldx = X.stride(0) if X.shape[0] > 1 else F
+            fold = (self._folds_col_scale(self._rowgroup_plan(F), ldx) and F % 4 == 0 and ldx % 4 == 0
+                    and X.data_ptr() % 16 == 0)
+            src = X if fold else self._staged(X, ldx, F, True)
+            Fp = ldx if fold else src.stride(0)
+            width = F if fold else Fp
+            spare = [torch.empty((self.n, width), dtype=torch.float32, device=self.device)] if order > 1 else []
+            if order > 2:    # second intermediate: the staged copy once hop 0 has read it
+                spare.append(torch.empty((self.n, width), dtype=torch.float32, device=self.device) if fold else src)
             for h in range(order):
                 last = h == order - 1
-                dst, ldd = (Y, F) if last else (spare, Fp)
-                self._hop(src, Fp, dst, ldd, F, True, False,
+                dst = Y if last else spare[h % 2]         # ping-pong: no hop reads what it writes
+                self._hop(src, Fp, dst, dst.stride(0), F, True, fold and h == 0,
                           _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2)
-                if not last:
-                    src, spare = dst, src         # ping-pong: no hop reads what it writes
+                src, Fp = dst, dst.stride(0)
         return Y
 
     # --------------------------------------------------------------- sampling

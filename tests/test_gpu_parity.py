@@ -303,6 +303,30 @@ def test_unit_weight_graph_rowgroup_and_plain_kernels(dev, F, order):
         lib.sgnn_tune_set(b"rg_R", 0)
 
 
+def test_column_scaling_inside_the_kernel_equals_a_scaled_copy(dev):
+    """A small graph's row-group plan scales the fetched rows of X inside the kernel when X
+    is 16-byte aligned, and otherwise works from a scaled, aligned copy: the same bits."""
+    n, F = 5000, 96
+    r, c = _hub_graph(n, seed=77)
+    key = np.unique(r.astype(np.int64) * n + c)
+    r, c = key // n, key % n
+    for val in (None, np.full(r.size, 2.0, np.float32)):          # pattern sum; diagonal correction
+        adj = _na().from_coo(r, c, val, n, dev)
+        plan = adj._rowgroup_plan(F)
+        assert plan is not None and adj._folds_col_scale(plan, F)
+        g = torch.Generator(device=dev); g.manual_seed(8)
+        X = torch.randn(n, F, device=dev, generator=g)
+        shifted = torch.empty(n * F + 1, device=dev)[1:].view(n, F)   # rows off the 16-byte grid
+        shifted.copy_(X)
+        assert X.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 != 0
+        assert torch.equal(adj.spmm(X), adj.spmm(shifted))
+        for order in (1, 3):
+            assert torch.equal(adj.propagate(X, order), adj.propagate(shifted, order))
+        rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, np.ones(r.size, np.float32) if val is None else val, n)
+        Xh = X.cpu().numpy()
+        _check_Y(adj.spmm(X), orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, Xh), rowptr, colidx, vals, dinv, Xh, 1)
+
+
 def test_strided_input_and_order_zero(dev):
     n = 3000
     r, c = _hub_graph(n, seed=77)
@@ -435,7 +459,19 @@ def test_rowgroup_entry_point_rejects_what_it_cannot_run(dev):
     assert call(X.data_ptr(), F + 4) == 0
     assert call(X.data_ptr() + 4, F + 4) == -4 and b"16-byte" in lib.sgnn_last_error()       # base off by one float
     assert call(X.data_ptr(), F + 3) == -4                                                     # odd row stride
-    assert call(X.data_ptr(), F + 4, dinv_col=_lib.ptr(adj.dinv)) == -4 and b"scaled" in lib.sgnn_last_error()
+    # column scaling inside the kernel: groups of 8 only (what a graph this small is planned with)
+    assert plan["R"] == 8 and call(X.data_ptr(), F + 4, dinv_col=_lib.ptr(adj.dinv)) == 0
+    lib.sgnn_tune_set(b"rg_R", 16)
+    try:
+        p16 = adj._rowgroup_plan(F)
+        ws16 = adj._rowgroup_ws(p16, F)
+        assert p16["R"] == 16
+        rc = lib.sgnn_spmm_rowgroup_f32(n, n, adj.nnz, F, 16, _lib.ptr(p16["buf"]), p16["bytes"], None, p16["items"],
+                                        p16["slots"], p16["n_long"], _lib.ptr(adj.dinv), _lib.ptr(adj.dinv), 1.0, None, 0,
+                                        X.data_ptr(), F + 4, _lib.ptr(Y), F, 0, _lib.ptr(ws16), ws16.numel(), st)
+        assert rc == -4 and b"only R = 8" in lib.sgnn_last_error()
+    finally:
+        lib.sgnn_tune_set(b"rg_R", 0)
     assert call(X.data_ptr(), F + 4, items=plan["items"] * 100 + 7) == -1
     if plan["slots"] > 0:
         assert call(X.data_ptr(), F + 4, ws_bytes=16) == -2
