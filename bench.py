@@ -294,7 +294,7 @@ def sgnn_epoch(adj, X, device, max_iter, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="reddit", help="reddit | reddit128 | products | rmat10m | pubmed")
     ap.add_argument("--order", type=int, default=1)

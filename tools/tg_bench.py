@@ -74,7 +74,7 @@ print(f"tile-group {t_tg:.3f} ms/hop   row-group {t_rg:.3f} ms/hop   normwise di
 if os.environ.get("TG_SWEEP"):
     adj.use_tilegroup = True
     lib = _lib.load()
-    for seg in (64, 128, 256):
+    for seg in (96, 128, 192, 256, 384, 512):
         lib.sgnn_tune_set(b"tg_seg", seg)
         adj._tg = None
         adj._tg_bufs = {}
