@@ -624,10 +624,12 @@ __device__ __forceinline__ __attribute__((address_space(3))) T* lds(uint32_t off
 }
 
 // One workgroup per (work item, feature slice); 8 wavefronts, wavefront w owns sub-tiles 2 w and 2 w + 1.
+// NT = the slice's N-tiles of 32 features that hold features below F (the last slice of a
+// width that is not a multiple of 128, every slice of a narrow one): the tiles beyond are
+// fetched with the row but neither read from LDS nor multiplied.
 template <int NT>
-__global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
+__device__ __forceinline__ void tg_run(const TgArgs& a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  if (a.state->flag != 0) return;   // X did not fit the fp16 planes: the fall-back kernel computes Y
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int item = blockIdx.x, slice = blockIdx.y;
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, nt);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, NT + nt);
+      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, 4 + nt);
       record(offs, bt);
       auto body = [&](auto tt_tag) {
         constexpr int TT = decltype(tt_tag)::value;
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
           acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), bl[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          bl[nt] = read_tile(base_a, base_b, NT + nt);
+          bl[nt] = read_tile(base_a, base_b, 4 + nt);
           if (nt == NT - 1) alo = pattern_lo(ahi);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -885,6 +887,15 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
+  if (a.state->flag != 0) return;   // X did not fit the fp16 planes: the fall-back kernel computes Y
+  const int tiles = (min(kSlice, a.F - int(blockIdx.y) * kSlice) + 31) / 32;   // workgroup-uniform
+  if (tiles >= 4) tg_run<4>(a);
+  else if (tiles == 3) tg_run<3>(a);
+  else if (tiles == 2) tg_run<2>(a);
+  else tg_run<1>(a);
 }
 
 // rows of a group cut into several items: add the items' partial rows in order, then the row epilogue
@@ -1152,12 +1163,12 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tg_spmm<4>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tg_spmm),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     attr_set = true;
   }
   sgnn::kernel_timer_begin(st);
-  hipLaunchKernelGGL((k_tg_spmm<4>), dim3(unsigned(items), unsigned(slices)), dim3(kWaves * kWave), kLdsBytes, st, a);
+  hipLaunchKernelGGL(k_tg_spmm, dim3(unsigned(items), unsigned(slices)), dim3(kWaves * kWave), kLdsBytes, st, a);
   HIP_TRY(hipGetLastError());
   sgnn::kernel_timer_end(st);
   if (long_groups > 0) {

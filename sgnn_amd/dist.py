@@ -447,7 +447,7 @@ class _LocalBlock:
         if self.use_tilegroup is False or a.nnz == 0 or a.w_off is None or a.corr is not None:
             return None        # (a diagonal of its own would need the block's rows of X at an offset)
         auto = self.use_tilegroup is None
-        if auto and (F < 96 or self.n_rows < 8192 or a.nnz < 32 * self.n_rows):
+        if auto and (F < 16 or self.n_rows < 8192 or a.nnz < 32 * self.n_rows):
             return None
         if self._tg is None:
             self._tg = tilegroup_build(self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a.device, auto)

@@ -301,13 +301,13 @@ class NormAdj:
 
     def _tilegroup_plan(self, F):
         """Tile-group plan, or None when that kernel does not apply (off-diagonal weights that
-        differ, narrow features, rows that share too few columns, switched off)."""
+        differ, fewer than 16 features, rows that share too few columns, switched off)."""
         if self.use_tilegroup is False or not self.use_rowgroup or self.nnz == 0:
             return None
         if self.w_off is None:
             return None
         auto = self.use_tilegroup is None
-        if auto and (F < 96 or self.n < 8192 or self.nnz < 32 * self.n):
+        if auto and (F < 16 or self.n < 8192 or self.nnz < 32 * self.n):
             return None
         if self._tg is None:
             self._tg = tilegroup_build(self.n, self.n, self.nnz, self.rowptr, self.colidx, self.device, auto)

@@ -21,7 +21,10 @@ def _graph(n, und_edges, seed, dev, weight=None):
 
 
 @pytest.mark.parametrize("n,edges,F,order", [(3000, 40_000, 128, 1), (3000, 40_000, 602, 2), (700, 9_000, 100, 1),
-                                             (5000, 200_000, 37, 3), (513, 3_000, 256, 1), (40, 100, 130, 2)])
+                                             (5000, 200_000, 37, 3), (513, 3_000, 256, 1), (40, 100, 130, 2),
+                                             # narrow widths and last slices of 1, 2 and 3 N-tiles of 32 features
+                                             (3000, 40_000, 16, 2), (2000, 30_000, 8, 1), (3000, 40_000, 65, 1),
+                                             (2000, 30_000, 96, 2), (2000, 30_000, 193, 1)])
 def test_tilegroup_matches_oracle(gpu_device, n, edges, F, order):
     adj, r, c, v = _graph(n, edges, seed=n + F, dev=gpu_device)
     rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
