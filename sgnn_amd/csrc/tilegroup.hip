@@ -682,7 +682,8 @@ __device__ __forceinline__ void tg_run(const TgArgs& a) {
   // whose latency every wavefront would sit out once per stage.
   auto issue = [&](int s, const int (&col)[4], int sf32, int steps) {
     const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
-    if (!(a.mode & 2)) {
+    // (lanes whose N-tile holds no feature below F fetch nothing: lane l moves segment l >> 4)
+    if (!(a.mode & 2) && (lane >> 4) < NT) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(8 * w + i) * 1024u);
