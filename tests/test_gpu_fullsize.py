@@ -52,6 +52,18 @@ def test_reddit_shape_full_size_properties(gpu_device):
         assert float(((Y - Y_csr).abs() / scale.clamp_min(1e-30)).max()) <= TOL
     adj.use_rowgroup = True
     adj.use_tilegroup = None
+    # narrow widths (SGC's 41 classes, GCN's hidden 16) take the tile-group kernel with fewer
+    # N-tiles per slice; a two-hop chain against the plain kernel
+    for Fn in (16, 41):
+        Xn = X[:, :Fn].contiguous()
+        Y_n = adj.propagate(Xn, 2)
+        assert int(adj._tg_bufs[Fn]["state"][1].item()) == 0
+        adj.use_rowgroup = False
+        Y_p = adj.propagate(Xn, 2)
+        sc = adj.propagate(adj.propagate(Xn.abs(), 1), 1)
+        adj.use_rowgroup = True
+        assert float((Y_n - Y_p).norm() / Y_p.norm()) <= TOL
+        assert float(((Y_n - Y_p).abs() / sc.clamp_min(1e-30)).max()) <= TOL
     Y_rg = Y_tg                                  # the properties below are checked on the kernel the benchmark runs
     s = adj.deg.sqrt()
     fixed = adj.propagate(s[:, None].expand(n, 64).contiguous(), 1)
