@@ -330,10 +330,13 @@ class NormAdj:
 
     def _folds_col_scale(self, plan, ldx):
         """True when the row-group kernel applies the column scaling itself for this plan and
-        an operand of row stride ``ldx``: groups of 8 (what small graphs take) on a pattern
-        plan, X below 4 GiB.  It saves a launch and a pass over X; large graphs are faster
-        with X scaled once up front."""
-        return plan is not None and plan["R"] == 8 and plan["gw"] is None and self.n * ldx * 4 < 2 ** 32 - 8192
+        an operand of row stride ``ldx``: a small graph (too few work items to fill the chip,
+        planned with groups of 8) on a pattern plan.  It saves a launch and a pass over X;
+        on large graphs the gather and multiply per fetched row cost more than that pass
+        (products shape: main kernel 5.96 ms against 5.33 ms)."""
+        small = self.n // 16 + self.nnz // 64 < 8192      # the rule of sgnn_rowgroup_config_for
+        return (plan is not None and small and plan["R"] == 8 and plan["gw"] is None
+                and self.n * ldx * 4 < 2 ** 32 - 8192)
 
     def _hop(self, X, ldx, Y, ldy, F, scale_rows, scale_cols, epilogue):
         """Enqueue one SpMM launch sequence: the row-group kernel when a plan
