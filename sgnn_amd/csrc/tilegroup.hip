@@ -905,30 +905,46 @@ __global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
   const int li = blockIdx.x;
   const int g = a.long_group[li], slot = a.long_slot[li], nseg = a.long_nseg[li];
   const int64_t stride = int64_t(kRows) * a.Fpad;
-  for (int rr = blockIdx.y; rr < kRows; rr += gridDim.y) {
+  // A workgroup takes the rows blockIdx.y, blockIdx.y + gridDim.y, ... of the group; its threads
+  // run over the (row, four features) pairs of those rows, so that none idles when F / 4 is not
+  // a multiple of the workgroup size (the partial rows are padded to whole slices and 16-byte
+  // aligned).  The partial sums of a pair are loaded four at a time and added in item order.
+  const int quads = (a.F + 3) / 4;
+  const int my_rows = (kRows - int(blockIdx.y) + int(gridDim.y) - 1) / int(gridDim.y);
+  const bool scale = a.dinv_row != nullptr;
+  for (int p = threadIdx.x; p < my_rows * quads; p += blockDim.x) {
+    const int rr = int(blockIdx.y) + (p / quads) * int(gridDim.y);
+    const int f4 = (p % quads) * 4;
     const int row = a.grows[int64_t(g) * kRows + rr];
     if (row < 0) continue;
-    const bool scale = a.dinv_row != nullptr;
     const float dr = scale ? a.dinv_row[row] : 1.0f;
     const float cr = a.corr != nullptr ? a.corr[row] * (a.dinv_col != nullptr ? a.dinv_col[row] : 1.0f) : 0.0f;
-    // four features per thread (the partial rows are padded to whole slices and 16-byte aligned)
-    for (int f4 = 4 * threadIdx.x; f4 < a.F; f4 += 4 * blockDim.x) {
-      const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f4;
-      f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-      for (int k = 0; k < nseg; ++k) s += *reinterpret_cast<const f32x4*>(pp + k * stride);
+    const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f4;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    for (; k + 4 <= nseg; k += 4) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(pp + (k + 0) * stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(pp + (k + 1) * stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(pp + (k + 2) * stride);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(pp + (k + 3) * stride);
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; k < nseg; ++k) s += *reinterpret_cast<const f32x4*>(pp + k * stride);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int f = f4 + j;
-        if (f >= a.F) break;
-        float y = s[j];
-        if (a.corr != nullptr) y = fmaf(a.w_off, y, cr * a.X[int64_t(row) * a.ldx + f]);
-        else if (a.w_off != 1.0f) y *= a.w_off;
-        if (scale) {
-          y = y * dr;
-          if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
-        }
-        a.Y[int64_t(row) * a.ldy + f] = y;
+    for (int j = 0; j < 4; ++j) {
+      const int f = f4 + j;
+      if (f >= a.F) break;
+      float y = s[j];
+      if (a.corr != nullptr) y = fmaf(a.w_off, y, cr * a.X[int64_t(row) * a.ldx + f]);
+      else if (a.w_off != 1.0f) y *= a.w_off;
+      if (scale) {
+        y = y * dr;
+        if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
       }
+      a.Y[int64_t(row) * a.ldy + f] = y;
     }
   }
 }
