@@ -534,6 +534,7 @@ int sgnn_tune_set(const char* key, int value) {
   else if (!std::strcmp(key, "rg_order")) sgnn::set_rowgroup_order(value);
   else if (!std::strcmp(key, "tg_seg")) sgnn::set_tilegroup_segment(value);
   else if (!std::strcmp(key, "tg_mode")) sgnn::set_tilegroup_mode(value);
+  else if (!std::strcmp(key, "tg_order")) sgnn::set_tilegroup_order(value);
   else if (!std::strcmp(key, "time_kernel")) { sgnn::g_timer_on = value != 0; sgnn::g_timer_used = 0; }
   else return fail(SGNN_ERR_INVALID, std::string("unknown tuning key ") + key);
   return SGNN_OK;

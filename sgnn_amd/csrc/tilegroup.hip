@@ -72,8 +72,8 @@ constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slac
 static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wavefront loads 16 rows of a stage");
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
 
-int g_seg_stages = 128;   // stages per work item; longer merged lists are cut (sgnn_tune_set("tg_seg", v))
-int g_order_cols = 4096;
+int g_seg_stages = 0;     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
+int g_order_cols = 0;     // > 0: work items ordered by column blocks of this width; 0: longest first (sgnn_tune_set("tg_order", v))
 int g_tg_mode = 0;         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA; results are then wrong
 
 struct TgState {          // device words shared by the split pass and the SpMM
@@ -293,12 +293,27 @@ __global__ void k_tg_run_steps(int64_t runs_cap, const int64_t* __restrict__ cou
 }
 
 // work items: a group's stages in pieces of about `seg` stages
-__global__ void k_tg_nseg(int64_t G, int seg, const uint32_t* __restrict__ gns, uint32_t* __restrict__ nseg,
+// Stages per work item.  Long items mean few partial rows to write and combine, short ones a
+// launch that 256 CUs finish together: 224 stages where the plan is large enough to make some
+// 450 items of that length (Reddit shape: 5.45-5.6 ms per hop from 192 to 288, 5.66 at 128,
+// 5.86 at 384), proportionally fewer for small plans (a rank's block of a partitioned graph),
+// never under 32.
+constexpr uint32_t kSegStages = 224, kSegStagesMin = 32, kItemsWanted = 448;
+
+__device__ __forceinline__ uint32_t tg_seg_for(uint32_t total_stages, int override_seg) {
+  if (override_seg > 0) return uint32_t(override_seg);
+  const uint32_t s = total_stages / kItemsWanted;
+  return s < kSegStagesMin ? kSegStagesMin : (s > kSegStages ? kSegStages : s);
+}
+
+__global__ void k_tg_nseg(int64_t G, int override_seg, const uint32_t* __restrict__ gns,
+                          const uint32_t* __restrict__ gstage0, uint32_t* __restrict__ nseg,
                           uint32_t* __restrict__ lseg, uint32_t* __restrict__ lflag) {
   int64_t g = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (g >= G) return;
+  const uint32_t seg = tg_seg_for(gstage0[G], override_seg);
   const uint32_t ns = gns[g];
-  const uint32_t pieces = ns > uint32_t(seg + seg / 4) ? (ns + seg - 1) / seg : 1u;   // an empty group still writes its zero rows
+  const uint32_t pieces = ns > seg + seg / 4 ? (ns + seg - 1) / seg : 1u;   // an empty group still writes its zero rows
   nseg[g] = pieces;
   lseg[g] = pieces > 1 ? pieces : 0u;
   lflag[g] = pieces > 1 ? 1u : 0u;
@@ -316,7 +331,7 @@ __global__ void k_tg_totals(int64_t G, const uint32_t* __restrict__ gstage0, con
   counts[3] = G > 0 ? int64_t(first[G - 1]) + nseg[G - 1] : 0;
   counts[4] = G > 0 ? int64_t(slot0[G - 1]) + lseg[G - 1] : 0;
   counts[5] = G > 0 ? int64_t(lidx[G - 1]) + lflag[G - 1] : 0;
-  counts[6] = seg;
+  counts[6] = tg_seg_for(uint32_t(stages), seg);
 }
 
 // ---- plan construction, phase 1: contents -----------------------------------------
@@ -409,13 +424,19 @@ __global__ void k_tg_items(int64_t G, const uint32_t* __restrict__ gns, const ui
   }
 }
 
-// Launch order: by the column block an item's first stage starts in, so that workgroups
-// running at the same time walk the same stretch of X and meet each other's rows in L2.
+// Launch order: longest item first, so that the tail of the launch is made of short items
+// (measured on the Reddit shape against ordering by the column block an item starts in, which
+// is what the row-group kernel's L2 reuse wanted: 5.5-5.65 ms per hop against 5.9; this
+// kernel's reuse happens inside a group, and the last long items of a launch idle the chip).
 __global__ void k_tg_item_keys(int64_t items, const int32_t* __restrict__ tmp, int64_t cap,
                                const int32_t* __restrict__ stage_col, int order_cols, uint64_t* __restrict__ keys) {
   int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (it >= items) return;
   const int64_t s0 = tmp[cap + it];
+  if (order_cols <= 0) {
+    keys[it] = (uint64_t(0x7fffffff - (tmp[2 * cap + it] - int32_t(s0))) << 32) | uint64_t(it);
+    return;
+  }
   keys[it] = (uint64_t(stage_col[s0 * kStageCols] / order_cols) << 32) | uint64_t(it);
 }
 
@@ -955,7 +976,8 @@ dim3 blocks_for(int64_t items, unsigned T = 256) { return dim3(unsigned((items +
 
 namespace sgnn {
 void set_tilegroup_mode(int m) { g_tg_mode = m; }
-void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 128; }
+void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 0; }
+void set_tilegroup_order(int cols) { g_order_cols = cols > 0 ? cols : 0; }
 }  // namespace sgnn
 
 extern "C" {
@@ -1041,7 +1063,7 @@ int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
                                   st));
   // work items
   const int seg = g_seg_stages;
-  hipLaunchKernelGGL(k_tg_nseg, blocks_for(w.G), dim3(T), 0, st, w.G, seg, w.gns, w.nseg, w.lseg, w.lflag);
+  hipLaunchKernelGGL(k_tg_nseg, blocks_for(w.G), dim3(T), 0, st, w.G, seg, w.gns, w.gstage0, w.nseg, w.lseg, w.lflag);
   HIP_TRY(hipGetLastError());
   pb = w.prim_bytes;
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.nseg, w.first, 0u, size_t(w.G), rocprim::plus<uint32_t>(), st));

@@ -74,9 +74,14 @@ print(f"tile-group {t_tg:.3f} ms/hop   row-group {t_rg:.3f} ms/hop   normwise di
 if os.environ.get("TG_SWEEP"):
     adj.use_tilegroup = True
     lib = _lib.load()
-    for seg in (96, 128, 192, 256, 384, 512):
-        lib.sgnn_tune_set(b"tg_seg", seg)
-        adj._tg = None
-        adj._tg_bufs = {}
-        adj.propagate(X, 1)
-        print(f"tg_seg {seg}: items {adj._tg['items']} partial slots {adj._tg['slots']}: {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
+    wls = {}
+    for order in (4096, 0):
+        lib.sgnn_tune_set(b"tg_order", order)
+        for seg in (128, 160, 192, 224, 256, 288, 320, 384):
+            lib.sgnn_tune_set(b"tg_seg", seg)
+            adj._tg = None
+            adj._tg_bufs = {}
+            adj.propagate(X, 1)
+            print(f"order {'column block' if order else 'longest first'} tg_seg {seg}: items {adj._tg['items']} partial slots {adj._tg['slots']}: {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
+    lib.sgnn_tune_set(b"tg_order", 0)
+    lib.sgnn_tune_set(b"tg_seg", 0)
