@@ -223,11 +223,20 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           (X and dinv_col as given to the split call, csr_workspace of
  *                           sgnn_spmm_workspace_bytes); rowptr == NULL: no fall-back is
  *                           launched and Y is left untouched when state's flag is set.
+ *                           The launch is one workgroup per CU; the workgroups take (work
+ *                           item, feature slice) pairs off a counter kept in `state`, which
+ *                           the call zeroes: two SpMM calls that share a `state` must not
+ *                           overlap (calls in one stream never do).
  */
 /* Diagnostics: cycle counters of tile-group runs made with tuning key "tg_mode" bit 16 set (kernel,
  * stage waits, next-stage issue, step loops, wavefronts, steps, stages; summed over wavefronts);
  * reading clears them.  No counterpart in the reference. */
 int sgnn_tilegroup_debug_counters(unsigned long long* out8);
+/* Diagnostics: four words per workgroup — wall-clock (100 MHz) start and end, CU id, stages
+ * walked — for the first `count` (at most 16384) workgroups of the last tile-group SpMM launch
+ * made with tuning key tg_mode bit 16 set; out is host memory of count * 32 bytes.  No
+ * reference counterpart. */
+int sgnn_tilegroup_debug_spans(unsigned long long* out, int64_t count);
 size_t sgnn_tilegroup_build_workspace_bytes(int64_t n_rows, int64_t nnz);
 size_t sgnn_tilegroup_plan_bytes(int64_t n_rows, int64_t stages, int64_t steps, int64_t items, int64_t long_groups);
 int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
@@ -242,7 +251,7 @@ size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F);
 int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
                             int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
                             const float* dinv_row, float w_off, const float* corr, const void* planes,
-                            size_t planes_bytes, const void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                            size_t planes_bytes, void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
                             size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                             const float* vals, const float* dinv_col, const float* X, int64_t ldx,
                             void* csr_workspace, size_t csr_workspace_bytes, void* stream);

@@ -60,6 +60,7 @@ SIGNATURES = {
                                        ctypes.c_float, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "sgnn_tilegroup_debug_counters": (c_int, [c_void_p]),
+    "sgnn_tilegroup_debug_spans": (c_int, [c_void_p, c_int64]),
     "sgnn_tilegroup_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgnn_tilegroup_plan_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "sgnn_tilegroup_analyze": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -81,7 +81,8 @@ struct TgState {          // device words shared by the split pass and the SpMM
   uint32_t flag;          // != 0: X cannot go through the fp16 planes
   float scale, inv_scale;
   uint32_t tiny;          // nonzero elements more than 2^33 below the largest magnitude
-  uint32_t pad[3];
+  uint32_t queue;         // next work index of the running SpMM launch (zeroed by the SpMM call)
+  uint32_t pad[2];
 };
 
 // ---- plan ------------------------------------------------------------------------
@@ -593,6 +594,8 @@ __global__ void k_tg_finish(TgState* __restrict__ state, uint32_t tiny_limit) {
 // cycle counts of a diagnostic run (mode bit 16): kernel, waits for a stage, issue of the next
 // stage, step loops; wavefronts that took part; steps
 __device__ unsigned long long g_tg_dbg[8];
+constexpr int kDbgSpans = 16384;
+__device__ unsigned long long g_tg_span[4 * kDbgSpans];   // diagnostics: wall-clock start and end, CU and stage count of the first workgroups
 
 // ---- the kernel -----------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -609,6 +612,7 @@ struct TgArgs {
   const int32_t *long_group, *long_slot, *long_nseg;
   const char* planes;
   const TgState* state;
+  uint32_t* queue;   // work counter of this launch (in the state words)
   const float* dinv_row;
   // diagonal of its own (A + A^T has weight 2 off the diagonal, A + I puts 1 on it): the
   // weighted row sum is w_off * (pattern sum) + corr[i] * x'_i with x' the operand as the
@@ -619,6 +623,7 @@ struct TgArgs {
   int32_t items, n_long, F, Fpad, epilogue;
   float w_off;
   int32_t mode;
+  int32_t slices;
 };
 
 // LDS-DMA: 64 lanes x 16 (4) bytes from per-lane global addresses to LDS [lds, lds + 1024 (256)).
@@ -649,11 +654,10 @@ __device__ __forceinline__ __attribute__((address_space(3))) T* lds(uint32_t off
 // width that is not a multiple of 128, every slice of a narrow one): the tiles beyond are
 // fetched with the row but neither read from LDS nor multiplied.
 template <int NT>
-__device__ __forceinline__ void tg_run(const TgArgs& a) {
+__device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const int slice, const int work) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int item = blockIdx.x, slice = blockIdx.y;
   const int g = a.item_group[item], s0 = a.item_s0[item], s1 = a.item_s1[item], out = a.item_out[item];
   constexpr uint32_t lds0 = 0;   // LDS address of smem: the dynamic segment follows the static one, and there is none
   const char* xs = a.planes + int64_t(slice) * a.slice_bytes;
@@ -738,6 +742,7 @@ __device__ __forceinline__ void tg_run(const TgArgs& a) {
   const bool dbg = (a.mode & 16) != 0;
   unsigned long long t_wait = 0, t_issue = 0, t_steps = 0, n_steps = 0;
   const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long wall_begin = dbg ? wall_clock64() : 0;   // 100 MHz, the same on every CU
   const int ns = s1 - s0;
   if (ns > 0) {   // the item's first stage: ids and step counts from global memory
     int col[4];
@@ -869,6 +874,15 @@ __device__ __forceinline__ void tg_run(const TgArgs& a) {
   }
   if (dbg && lane == 0) {
     atomicAdd(&g_tg_dbg[0], __builtin_amdgcn_s_memtime() - t_begin);
+    if (w == 0) atomicAdd(&g_tg_dbg[7], wall_clock64() - wall_begin);   // workgroup residence, summed
+    if (w == 0 && work < kDbgSpans) {
+      g_tg_span[4 * work] = wall_begin;
+      g_tg_span[4 * work + 1] = wall_clock64();
+      // XCC_ID (hardware register 20) and HW_ID (4: CU in bits 8-11, SH 12, SE 13-15)
+      g_tg_span[4 * work + 2] = ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 16) |
+                                      ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xFFu);
+      g_tg_span[4 * work + 3] = (unsigned long long)ns;
+    }
     atomicAdd(&g_tg_dbg[1], t_wait);
     atomicAdd(&g_tg_dbg[2], t_issue);
     atomicAdd(&g_tg_dbg[3], t_steps);
@@ -911,13 +925,37 @@ __device__ __forceinline__ void tg_run(const TgArgs& a) {
   }
 }
 
+// Work order: slice-major, inside a slice the items longest first (the plan's order).  Slices
+// stay together in time, which keeps a slice's hot rows in L2 (slice index fastest was tried:
+// 9 % slower), and a slice ends on its short items; launching the long items of all slices
+// ahead of all the short ones was tried and made no difference once the counter was in.
 __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
   if (a.state->flag != 0) return;   // X did not fit the fp16 planes: the fall-back kernel computes Y
-  const int tiles = (min(kSlice, a.F - int(blockIdx.y) * kSlice) + 31) / 32;   // workgroup-uniform
-  if (tiles >= 4) tg_run<4>(a);
-  else if (tiles == 3) tg_run<3>(a);
-  else if (tiles == 2) tg_run<2>(a);
-  else tg_run<1>(a);
+  const int total = a.items * a.slices;
+  // One workgroup per CU for the whole launch, taking (item, slice) pairs off a counter: a
+  // workgroup holds all of a CU's LDS, so a fresh one can only be placed when the last has gone,
+  // and between two workgroups of a one-per-pair grid a CU sat idle for tens of microseconds
+  // (Reddit shape: 5.27 ms per hop with the counter against 5.48 ms with one workgroup per
+  // pair).  Every wavefront leaves through the same test of b.
+  int* next = reinterpret_cast<int*>(smem + kTableBytes - 16);   // behind the pattern table, before the ring
+  for (;;) {
+    int b = blockIdx.x;
+    if (!(a.mode & 128)) {
+      if (threadIdx.x == 0) *next = int(atomicAdd(a.queue, 1u));
+      __syncthreads();
+      b = __builtin_amdgcn_readfirstlane(*next);
+      __syncthreads();   // everyone has read it before the next round writes it; the last item's LDS reads are over
+    }
+    if (b >= total) break;
+    const int slice = b / a.items, item = b - slice * a.items;
+    const int tiles = (min(kSlice, a.F - slice * kSlice) + 31) / 32;   // workgroup-uniform
+    if (tiles >= 4) tg_run<4>(a, item, slice, b);
+    else if (tiles == 3) tg_run<3>(a, item, slice, b);
+    else if (tiles == 2) tg_run<2>(a, item, slice, b);
+    else tg_run<1>(a, item, slice, b);
+    if (a.mode & 128) break;   // diagnostics: one workgroup per (item, slice) pair
+  }
 }
 
 // rows of a group cut into several items: add the items' partial rows in order, then the row epilogue
@@ -987,6 +1025,15 @@ int sgnn_tilegroup_debug_counters(unsigned long long* out8) {
   unsigned long long zero[8] = {};
   HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tg_dbg), sizeof(zero)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tg_dbg), zero, sizeof(zero)));
+  return SGNN_OK;
+}
+
+// diagnostics: per workgroup of the last k_tg_spmm launch made with tg_mode bit 16 set, four
+// words: wall-clock (100 MHz) start and end, CU (XCC << 16 | SE, SH, CU bits), stages walked;
+// at most 16384 workgroups are kept
+int sgnn_tilegroup_debug_spans(unsigned long long* out, int64_t count) {
+  if (!out || count < 0 || count > kDbgSpans) return fail(SGNN_ERR_INVALID, "at most 16384 spans are kept");
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tg_span), size_t(count) * 32));
   return SGNN_OK;
 }
 
@@ -1165,7 +1212,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
                             int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
                             const float* dinv_row, float w_off, const float* corr, const void* planes,
                             size_t planes_bytes,
-                            const void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                            void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
                             size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                             const float* vals, const float* dinv_col, const float* X, int64_t ldx,
                             void* csr_workspace, size_t csr_workspace_bytes, void* stream) {
@@ -1185,7 +1232,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
     return fail(SGNN_ERR_WORKSPACE, "tile-group spmm workspace too small");
   if (reinterpret_cast<uintptr_t>(workspace) % 16) return fail(SGNN_ERR_INVALID, "workspace must be 16-byte aligned");
   const int64_t slices = (F + kSlice - 1) / kSlice;
-  if (slices > 65535) return fail(SGNN_ERR_INVALID, "too many feature slices for one launch");
+  if (slices * items >= (int64_t(1) << 31)) return fail(SGNN_ERR_INVALID, "too many workgroups for one launch");
   TgArgs a{};
   a.grows = p.grows; a.stage_col = p.stage_col; a.step0 = p.step0;
   a.step_slots = p.step_slots; a.step_bits = p.step_bits;
@@ -1193,12 +1240,14 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   a.long_group = p.long_group; a.long_slot = p.long_slot; a.long_nseg = p.long_nseg;
   a.planes = static_cast<const char*>(planes);
   a.state = static_cast<const TgState*>(state);
+  a.queue = &static_cast<TgState*>(state)->queue;
   a.dinv_row = dinv_row; a.Y = Y; a.partial = static_cast<float*>(workspace);
   a.corr = corr; a.X = X; a.dinv_col = dinv_col; a.ldx = ldx;
   a.ldy = ldy; a.slice_bytes = n_cols * kRowBytes;
   a.items = int32_t(items); a.n_long = int32_t(long_groups);
   a.F = int32_t(F); a.Fpad = int32_t(slices * kSlice); a.epilogue = epilogue; a.w_off = w_off;
   a.mode = g_tg_mode;
+  a.slices = int32_t(slices);
   hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1207,7 +1256,17 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
     attr_set = true;
   }
   sgnn::kernel_timer_begin(st);
-  hipLaunchKernelGGL(k_tg_spmm, dim3(unsigned(items), unsigned(slices)), dim3(kWaves * kWave), kLdsBytes, st, a);
+  // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
+  static int n_cus = 0;
+  if (n_cus == 0) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cus <= 0) n_cus = 256;
+  }
+  HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st));
+  const int64_t wgs = (items * slices < n_cus || (a.mode & 128)) ? items * slices : n_cus;
+  hipLaunchKernelGGL(k_tg_spmm, dim3(unsigned(wgs)), dim3(kWaves * kWave), kLdsBytes, st, a);
   HIP_TRY(hipGetLastError());
   sgnn::kernel_timer_end(st);
   if (long_groups > 0) {

@@ -59,9 +59,44 @@ if os.environ.get("TG_CYCLES"):
     for extra in [int(v) for v in os.environ["TG_CYCLES"].split(",")]:
         lib.sgnn_tune_set(b"tg_mode", 16 | extra)
         adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
+        lib.sgnn_tune_set(b"time_kernel", 1)
         adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
+        k_ms, k_n = _lib.kernel_time_ms()
+        lib.sgnn_tune_set(b"time_kernel", 0)
         lib.sgnn_tune_set(b"tg_mode", 0)
         tot, wait, issue, steps, waves, nsteps, nstages = [out[i] for i in range(7)]
+        # workgroup residence (100 MHz wall clock, summed) against 256 CUs busy for the whole kernel
+        nwg = min(16384, adj._tg["items"] * ((F + 127) // 128))
+        spans = (ctypes.c_ulonglong * (4 * nwg))()
+        lib.sgnn_tilegroup_debug_spans(spans, nwg)
+        import numpy as np
+        sp = np.array(spans[:], dtype=np.int64).reshape(nwg, 4)
+        t0, t1 = sp[:, 0].min(), sp[:, 1].max()
+        ev = np.concatenate((np.stack((sp[:, 0], np.ones(nwg, np.int64)), 1), np.stack((sp[:, 1], -np.ones(nwg, np.int64)), 1)))
+        ev = ev[np.argsort(ev[:, 0], kind="stable")]
+        live = np.cumsum(ev[:, 1])
+        dt = np.diff(ev[:, 0], append=ev[-1, 0])
+        span = float(t1 - t0)
+        print(f"workgroups {nwg}: first start to last end {span * 1e-5:.3f} ms; mean resident {float((live * dt).sum()) / span:.1f}; "
+              f"time with all 256 resident {float(dt[live >= 256].sum()) / span * 100:.1f}%, with under 200 {float(dt[live < 200].sum()) / span * 100:.1f}%")
+        deciles = [float((live * dt)[(ev[:, 0] >= t0 + span * k / 10) & (ev[:, 0] < t0 + span * (k + 1) / 10)].sum()) / (span / 10) for k in range(10)]
+        print("mean resident workgroups per tenth of the kernel:", [round(v) for v in deciles])
+        dur = (sp[:, 1] - sp[:, 0]) * 1e-2
+        gaps, busy_by_xcc, end_by_xcc = [], {}, {}
+        for cu in np.unique(sp[:, 2]):
+            mine = sp[sp[:, 2] == cu]
+            mine = mine[np.argsort(mine[:, 0])]
+            gaps.extend(((mine[1:, 0] - mine[:-1, 1]) * 1e-2).tolist())
+            x = int(cu) >> 16
+            busy_by_xcc[x] = busy_by_xcc.get(x, 0.0) + float((mine[:, 1] - mine[:, 0]).sum()) * 1e-5
+            end_by_xcc[x] = max(end_by_xcc.get(x, 0.0), float(mine[:, 1].max() - t0) * 1e-5)
+        gaps = np.array(gaps)
+        print(f"distinct CUs {len(np.unique(sp[:, 2]))}; gap between consecutive workgroups of a CU, us: median {np.median(gaps):.1f} mean {gaps.mean():.1f} "
+              f"p90 {np.percentile(gaps, 90):.1f} max {gaps.max():.0f}; summed {gaps.sum() * 1e-3 / 256:.3f} ms per CU")
+        print("per XCC: busy ms per CU", {k: round(v / 32, 3) for k, v in sorted(busy_by_xcc.items())}, "last end ms", {k: round(v, 3) for k, v in sorted(end_by_xcc.items())})
+        print(f"us per stage by workgroup length: long (>=150 stages) {dur[sp[:, 3] >= 150].sum() / sp[sp[:, 3] >= 150, 3].sum():.2f}, short {dur[sp[:, 3] < 150].sum() / max(1, sp[sp[:, 3] < 150, 3].sum()):.2f}")
+        print(f"workgroup duration us: mean {dur.mean():.0f} max {dur.max():.0f}; last 256 to start: mean {dur[np.argsort(sp[:, 0])[-256:]].mean():.0f}")
+        print(f"mode {extra}: kernel {k_ms / max(k_n, 1):.3f} ms; CUs occupied {out[7] * 1e-5 / (256 * k_ms / max(k_n, 1)) * 100:.1f}% of the kernel's time", flush=True)
         print(f"mode {extra}: per wavefront: total {tot / waves:.0f} cycles; stage wait {100 * wait / tot:.1f}% issue {100 * issue / tot:.1f}% "
               f"steps {100 * steps / tot:.1f}%; {steps / max(nsteps, 1):.0f} cycles per step, {nsteps / nstages:.2f} steps and "
               f"{wait / nstages:.0f} + {issue / nstages:.0f} + {steps / nstages:.0f} cycles per stage", flush=True)
@@ -74,14 +109,8 @@ print(f"tile-group {t_tg:.3f} ms/hop   row-group {t_rg:.3f} ms/hop   normwise di
 if os.environ.get("TG_SWEEP"):
     adj.use_tilegroup = True
     lib = _lib.load()
-    wls = {}
-    for order in (4096, 0):
-        lib.sgnn_tune_set(b"tg_order", order)
-        for seg in (128, 160, 192, 224, 256, 288, 320, 384):
-            lib.sgnn_tune_set(b"tg_seg", seg)
-            adj._tg = None
-            adj._tg_bufs = {}
-            adj.propagate(X, 1)
-            print(f"order {'column block' if order else 'longest first'} tg_seg {seg}: items {adj._tg['items']} partial slots {adj._tg['slots']}: {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
-    lib.sgnn_tune_set(b"tg_order", 0)
-    lib.sgnn_tune_set(b"tg_seg", 0)
+    for rep in range(3):
+        for mode in (0, 128):
+            lib.sgnn_tune_set(b"tg_mode", mode)
+            print(f"{'one workgroup per pair' if mode else 'one workgroup per CU, work counter'}: {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
+    lib.sgnn_tune_set(b"tg_mode", 0)

@@ -46,3 +46,46 @@ for cap in (64, 74, 89, 96, 112):
     over = tot > cap
     print(f"cap {cap}: {over.float().mean() * 100:.1f}% of stages hold {tot[over].sum() / tot.sum() * 100:.1f}% of steps; "
           f"groups with a stage over it: {(gmax > cap).sum().item()} of {G}, holding {gsum[gmax > cap].sum() / tot.sum() * 100:.1f}% of steps")
+
+# ---- launch-order simulation: greedy list scheduling of (item, slice) workgroups on 256 CUs ----
+import heapq
+ns = (gst[1:] - gst[:-1]).cpu()
+stage_cost = (1500 + 550 * wave_now.max(1).values.float()).cpu()          # ticks: issue + the slowest wavefront's steps
+cum = torch.cat((torch.zeros(1), stage_cost.cumsum(0)))
+gst_c = gst.cpu()
+total = int(gst_c[-1])
+slice_w = [1.0, 1.0, 1.0, 1.0, 0.85]                                       # the fifth slice of F = 602 has 3 of 4 tiles
+
+
+def items_for(seg):
+    out = []
+    for g in range(G):
+        n_g, s0 = int(ns[g]), int(gst_c[g])
+        pieces = (n_g + seg - 1) // seg if n_g > seg + seg // 4 else 1
+        for k in range(pieces):
+            a, b = s0 + n_g * k // pieces, s0 + n_g * (k + 1) // pieces
+            out.append((b - a, float(cum[b] - cum[a]) + 6000.0))          # stages, ticks incl. start-up and write-out
+    return out
+
+
+def makespan(order):
+    free = [0.0] * 256
+    heapq.heapify(free)
+    end = 0.0
+    for c in order:
+        t = heapq.heappop(free) + c
+        end = max(end, t)
+        heapq.heappush(free, t)
+    return end
+
+
+for seg in (128, max(32, min(224, total // 448)), 320):
+    its = sorted(items_for(seg), key=lambda x: -x[0])
+    ideal = sum(c for _, c in its) * sum(slice_w) / 256
+    plain = [c * w for w in slice_w for _, c in its]
+    front = [c * w for w in slice_w for n_, c in its if n_ >= 96] + [c * w for w in slice_w for n_, c in its if n_ < 96]
+    glob = sorted(plain, reverse=True)
+    rev = [c * w for w in reversed(slice_w) for _, c in its]
+    print(f"seg {seg}: {len(its)} items; simulated makespan / ideal: slice-major longest-first {makespan(plain) / ideal:.3f}, "
+          f"long items of all slices first {makespan(front) / ideal:.3f}, all workgroups longest-first {makespan(glob) / ideal:.3f}, "
+          f"cheap slice first {makespan(rev) / ideal:.3f}")
