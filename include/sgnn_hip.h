@@ -232,10 +232,11 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  * stage waits, next-stage issue, step loops, wavefronts, steps, stages; summed over wavefronts);
  * reading clears them.  No counterpart in the reference. */
 int sgnn_tilegroup_debug_counters(unsigned long long* out8);
-/* Diagnostics: four words per workgroup — wall-clock (100 MHz) start and end, CU id, stages
- * walked — for the first `count` (at most 16384) workgroups of the last tile-group SpMM launch
- * made with tuning key tg_mode bit 16 set; out is host memory of count * 32 bytes.  No
- * reference counterpart. */
+/* Diagnostics: eight words per unit of work (item, feature slice) — wall clock (100 MHz) at the
+ * start and the end of its stage loop, CU id, stages walked, wall clock when wavefront 0 had
+ * written its rows, at entry, when the whole workgroup had fetched its next unit, one spare — for
+ * the first `count` (at most 16384) units of the last tile-group SpMM launch made with tuning
+ * key tg_mode bit 16 set; out is host memory of count * 64 bytes.  No reference counterpart. */
 int sgnn_tilegroup_debug_spans(unsigned long long* out, int64_t count);
 size_t sgnn_tilegroup_build_workspace_bytes(int64_t n_rows, int64_t nnz);
 size_t sgnn_tilegroup_plan_bytes(int64_t n_rows, int64_t stages, int64_t steps, int64_t items, int64_t long_groups);

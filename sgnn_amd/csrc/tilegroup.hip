@@ -595,7 +595,7 @@ __global__ void k_tg_finish(TgState* __restrict__ state, uint32_t tiny_limit) {
 // stage, step loops; wavefronts that took part; steps
 __device__ unsigned long long g_tg_dbg[8];
 constexpr int kDbgSpans = 16384;
-__device__ unsigned long long g_tg_span[4 * kDbgSpans];   // diagnostics: wall-clock start and end, CU and stage count of the first workgroups
+__device__ unsigned long long g_tg_span[8 * kDbgSpans];   // diagnostics, eight words per unit of work (see sgnn_tilegroup_debug_spans)
 
 // ---- the kernel -----------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -656,6 +656,7 @@ __device__ __forceinline__ __attribute__((address_space(3))) T* lds(uint32_t off
 template <int NT>
 __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const int slice, const int work) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const unsigned long long wall_entry = (a.mode & 16) ? wall_clock64() : 0;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = a.item_group[item], s0 = a.item_s0[item], s1 = a.item_s1[item], out = a.item_out[item];
@@ -876,12 +877,13 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     atomicAdd(&g_tg_dbg[0], __builtin_amdgcn_s_memtime() - t_begin);
     if (w == 0) atomicAdd(&g_tg_dbg[7], wall_clock64() - wall_begin);   // workgroup residence, summed
     if (w == 0 && work < kDbgSpans) {
-      g_tg_span[4 * work] = wall_begin;
-      g_tg_span[4 * work + 1] = wall_clock64();
+      g_tg_span[8 * work] = wall_begin;
+      g_tg_span[8 * work + 1] = wall_clock64();
       // XCC_ID (hardware register 20) and HW_ID (4: CU in bits 8-11, SH 12, SE 13-15)
-      g_tg_span[4 * work + 2] = ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 16) |
+      g_tg_span[8 * work + 2] = ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 16) |
                                       ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xFFu);
-      g_tg_span[4 * work + 3] = (unsigned long long)ns;
+      g_tg_span[8 * work + 3] = (unsigned long long)ns;
+      g_tg_span[8 * work + 5] = wall_entry;
     }
     atomicAdd(&g_tg_dbg[1], t_wait);
     atomicAdd(&g_tg_dbg[2], t_issue);
@@ -891,19 +893,33 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     atomicAdd(&g_tg_dbg[6], (unsigned long long)ns);
   }
 
-  // accumulator register v of a lane: row (v & 3) + 8 (v >> 2) + 4 h of the sub-tile, feature lane & 31 of the N-tile
+  // Accumulator register v of a lane: row (v & 3) + 8 (v >> 2) + 4 h of the sub-tile, feature
+  // lane & 31 of the N-tile.  The wavefront's 64 rows and their scales are looked up once, one
+  // per lane (a coalesced load and a gather), and handed out by v_readlane: looked up row by
+  // row, two dependent loads stood in front of every one of the 32 row pairs and writing the
+  // rows out took 40 us of a 380 us unit of work.
   const float inv_scale = a.state->inv_scale;
+  const int my_row = a.grows[int64_t(g) * kRows + 2 * kSub * w + lane];
+  float my_dr = 1.0f, my_cr = 0.0f;
+  if (out < 0 && my_row >= 0) {
+    if (a.dinv_row != nullptr) my_dr = a.dinv_row[my_row];
+    if (a.corr != nullptr) my_cr = a.corr[my_row] * (a.dinv_col != nullptr ? a.dinv_col[my_row] : 1.0f);
+  }
+  auto pick = [&](int x, int src) {   // lane src (h = 0) or src + 4 (h = 1) of x; src is a constant
+    const int lo = __builtin_amdgcn_readlane(x, src), hi = __builtin_amdgcn_readlane(x, src + 4);
+    return h ? hi : lo;
+  };
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int t = 2 * w + tt;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
+      const int src = kSub * tt + (v & 3) + 8 * (v >> 2);
       const int rr = kSub * t + (v & 3) + 8 * (v >> 2) + 4 * h;
-      const int row = a.grows[int64_t(g) * kRows + rr];
+      const int row = pick(my_row, src);
       if (row < 0) continue;
-      float dr = 1.0f, cr = 0.0f;
-      if (out < 0 && a.dinv_row != nullptr) dr = a.dinv_row[row];
-      if (out < 0 && a.corr != nullptr) cr = a.corr[row] * (a.dinv_col != nullptr ? a.dinv_col[row] : 1.0f);
+      const float dr = __builtin_bit_cast(float, pick(__builtin_bit_cast(int, my_dr), src));
+      const float cr = __builtin_bit_cast(float, pick(__builtin_bit_cast(int, my_cr), src));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int f = slice * kSlice + nt * 32 + (lane & 31);
@@ -923,6 +939,7 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
       }
     }
   }
+  if (dbg && lane == 0 && w == 0 && work < kDbgSpans) g_tg_span[8 * work + 4] = wall_clock64();   // wavefront 0 has written its rows
 }
 
 // Work order: slice-major, inside a slice the items longest first (the plan's order).  Slices
@@ -939,6 +956,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   // (Reddit shape: 5.27 ms per hop with the counter against 5.48 ms with one workgroup per
   // pair).  Every wavefront leaves through the same test of b.
   int* next = reinterpret_cast<int*>(smem + kTableBytes - 16);   // behind the pattern table, before the ring
+  int prev = -1;
   for (;;) {
     int b = blockIdx.x;
     if (!(a.mode & 128)) {
@@ -946,6 +964,8 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
       __syncthreads();
       b = __builtin_amdgcn_readfirstlane(*next);
       __syncthreads();   // everyone has read it before the next round writes it; the last item's LDS reads are over
+      if ((a.mode & 16) && threadIdx.x == 0 && prev >= 0 && prev < kDbgSpans) g_tg_span[8 * prev + 6] = wall_clock64();
+      prev = b;
     }
     if (b >= total) break;
     const int slice = b / a.items, item = b - slice * a.items;
@@ -1028,12 +1048,14 @@ int sgnn_tilegroup_debug_counters(unsigned long long* out8) {
   return SGNN_OK;
 }
 
-// diagnostics: per workgroup of the last k_tg_spmm launch made with tg_mode bit 16 set, four
-// words: wall-clock (100 MHz) start and end, CU (XCC << 16 | SE, SH, CU bits), stages walked;
-// at most 16384 workgroups are kept
+// diagnostics: per unit of work (item, slice) of the last k_tg_spmm launch made with tg_mode bit
+// 16 set, eight words: wall clock (100 MHz) at the start and the end of the stage loop, CU
+// (XCC << 16 | SE, SH, CU bits), stages walked, wall clock when wavefront 0 had written its
+// rows, at entry, and when the whole workgroup had fetched its next unit; one spare.  At most
+// 16384 units are kept
 int sgnn_tilegroup_debug_spans(unsigned long long* out, int64_t count) {
   if (!out || count < 0 || count > kDbgSpans) return fail(SGNN_ERR_INVALID, "at most 16384 spans are kept");
-  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tg_span), size_t(count) * 32));
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tg_span), size_t(count) * 64));
   return SGNN_OK;
 }
 

@@ -57,7 +57,7 @@ if os.environ.get("TG_CYCLES"):
     out = (ctypes.c_ulonglong * 8)()
     fn = lib.sgnn_tilegroup_debug_counters
     for extra in [int(v) for v in os.environ["TG_CYCLES"].split(",")]:
-        lib.sgnn_tune_set(b"tg_mode", 16 | extra)
+        lib.sgnn_tune_set(b"tg_mode", 16 | extra)   # extra: 1 no steps, 2 no row DMA
         adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
         lib.sgnn_tune_set(b"time_kernel", 1)
         adj.propagate(X, 1); torch.cuda.synchronize(); fn(out)
@@ -67,10 +67,10 @@ if os.environ.get("TG_CYCLES"):
         tot, wait, issue, steps, waves, nsteps, nstages = [out[i] for i in range(7)]
         # workgroup residence (100 MHz wall clock, summed) against 256 CUs busy for the whole kernel
         nwg = min(16384, adj._tg["items"] * ((F + 127) // 128))
-        spans = (ctypes.c_ulonglong * (4 * nwg))()
+        spans = (ctypes.c_ulonglong * (8 * nwg))()
         lib.sgnn_tilegroup_debug_spans(spans, nwg)
         import numpy as np
-        sp = np.array(spans[:], dtype=np.int64).reshape(nwg, 4)
+        sp = np.array(spans[:], dtype=np.int64).reshape(nwg, 8)
         t0, t1 = sp[:, 0].min(), sp[:, 1].max()
         ev = np.concatenate((np.stack((sp[:, 0], np.ones(nwg, np.int64)), 1), np.stack((sp[:, 1], -np.ones(nwg, np.int64)), 1)))
         ev = ev[np.argsort(ev[:, 0], kind="stable")]
@@ -81,6 +81,11 @@ if os.environ.get("TG_CYCLES"):
               f"time with all 256 resident {float(dt[live >= 256].sum()) / span * 100:.1f}%, with under 200 {float(dt[live < 200].sum()) / span * 100:.1f}%")
         deciles = [float((live * dt)[(ev[:, 0] >= t0 + span * k / 10) & (ev[:, 0] < t0 + span * (k + 1) / 10)].sum()) / (span / 10) for k in range(10)]
         print("mean resident workgroups per tenth of the kernel:", [round(v) for v in deciles])
+        ok = sp[:, 6] > 0
+        print(f"per unit, us (median / mean): entry to first stage issued {np.median(sp[:, 0] - sp[:, 5]) * 1e-2:.1f} / {(sp[:, 0] - sp[:, 5]).mean() * 1e-2:.1f}; "
+              f"stage loop {np.median(sp[:, 1] - sp[:, 0]) * 1e-2:.1f} / {(sp[:, 1] - sp[:, 0]).mean() * 1e-2:.1f}; "
+              f"wavefront 0 writing its rows {np.median(sp[:, 4] - sp[:, 1]) * 1e-2:.1f} / {(sp[:, 4] - sp[:, 1]).mean() * 1e-2:.1f}; "
+              f"until the workgroup has its next unit {np.median((sp[:, 6] - sp[:, 4])[ok]) * 1e-2:.1f} / {(sp[:, 6] - sp[:, 4])[ok].mean() * 1e-2:.1f}")
         dur = (sp[:, 1] - sp[:, 0]) * 1e-2
         gaps, busy_by_xcc, end_by_xcc = [], {}, {}
         for cu in np.unique(sp[:, 2]):
