@@ -1271,21 +1271,23 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   a.mode = g_tg_mode;
   a.slices = int32_t(slices);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // per device: the attribute belongs to the device's copy of the kernel, and the number of
+  // workgroups to the device's CUs (a process may drive more than one GPU)
+  static bool attr_set[64] = {};
+  static int cus_of[64] = {};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(SGNN_ERR_INVALID, "device ordinal out of range");
+  if (!attr_set[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tg_spmm),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    attr_set = true;
+    HIP_TRY(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus_of[dev] <= 0) cus_of[dev] = 256;
+    attr_set[dev] = true;
   }
-  sgnn::kernel_timer_begin(st);
   // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
-  static int n_cus = 0;
-  if (n_cus == 0) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (n_cus <= 0) n_cus = 256;
-  }
+  const int n_cus = cus_of[dev];
+  sgnn::kernel_timer_begin(st);
   HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st));
   const int64_t wgs = (items * slices < n_cus || (a.mode & 128)) ? items * slices : n_cus;
   hipLaunchKernelGGL(k_tg_spmm, dim3(unsigned(wgs)), dim3(kWaves * kWave), kLdsBytes, st, a);

@@ -35,6 +35,13 @@ the GPU instead of bouncing through host memory on every call (model/SGNN.py:404
 every ``run`` — the first layer's input never changes, so 2*BP_count of its 2*BP_count+1
 propagations disappear.
 
+The label head ``Wt`` is a trained parameter on every device.  In the reference it is
+trained only on the CPU: with a GPU device, ``self.Wt = get_weight_initial(...).to(device)``
+(model/SGNN.py:376) makes a copy that is not a leaf and not in ``parameters()``, so Adam
+never updates it there and the head stays a random projection.  The end-to-end golden was
+captured from the reference on the CPU, where it trains; accuracies of a reference run on
+CUDA are not comparable with the ones produced here.
+
 An optimiser iteration itself runs on the library's own kernels where its shape allows:
 the batch projection with the row gather and the inner activation folded in
 (``_BatchProject``, ``_DenseProject``), the label head with its loss and gradients
