@@ -74,7 +74,7 @@ static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned s
 
 int g_seg_stages = 0;     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
 int g_order_cols = 0;     // > 0: work items ordered by column blocks of this width; 0: longest first (sgnn_tune_set("tg_order", v))
-int g_tg_mode = 0;         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA; results are then wrong
+int g_tg_mode = 0;         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only; results are then wrong
 
 struct TgState {          // device words shared by the split pass and the SpMM
   uint32_t amax_bits;     // bit pattern of max |scale_row * x|
@@ -714,8 +714,9 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
       for (int i = 0; i < 8; ++i) {
         const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(8 * w + i) * 1024u);
         const uint32_t off = src_off + uint32_t(i & 1) * 256u;
-        if (small) tg_dma16_off(xs, (uint32_t(col[i >> 1]) << 9) | off, dst);
-        else tg_dma16(xs + int64_t(col[i >> 1]) * kRowBytes + off, dst);
+        const int c = (a.mode & 64) ? (col[i >> 1] & 4095) : col[i >> 1];   // diagnostics: every fetch an L2 hit
+        if (small) tg_dma16_off(xs, (uint32_t(c) << 9) | off, dst);
+        else tg_dma16(xs + int64_t(c) * kRowBytes + off, dst);
       }
     }
     const int64_t sf = sf32;
@@ -909,6 +910,7 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     const int lo = __builtin_amdgcn_readlane(x, src), hi = __builtin_amdgcn_readlane(x, src + 4);
     return h ? hi : lo;
   };
+  if (a.mode & 32) return;   // diagnostics: nothing written
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int t = 2 * w + tt;
