@@ -118,7 +118,21 @@ def test_rmat10m_shape_full_size_properties(gpu_device):
     some = scale > 0                  # 1.3e9 normal draws hold a few exact zeros (isolated nodes keep them)
     assert float(diff[~some].sum()) == 0.0
     assert float((diff[some] / scale[some]).max()) <= TOL
-    del Y_csr, scale, diff, some
+    # The tile-group kernel does not pay on this graph (its rows share almost no columns) and is
+    # not chosen for it, but forced it must still be right: with 10^7 nodes a feature slice of
+    # the operand planes spans 5.1 GB, the only case in which that kernel addresses the rows it
+    # fetches with 64-bit offsets.
+    adj.use_rowgroup, adj.use_tilegroup = True, True
+    Y_tg = adj.propagate(X, 1)
+    assert adj._tg, "tile-group plan was not used"
+    assert n * 512 > (1 << 32)
+    assert float((Y_tg - Y_csr).norm() / Y_csr.norm()) <= TOL
+    diff = (Y_tg - Y_csr).abs()
+    assert float(diff[~some].sum()) == 0.0
+    assert float((diff[some] / scale[some]).max()) <= TOL
+    adj.use_tilegroup = None
+    adj._tg, adj._tg_bufs = None, {}
+    del Y_csr, Y_tg, scale, diff, some
     adj.use_rowgroup = True
     s = adj.deg.sqrt()
     fixed = adj.propagate(s[:, None].expand(n, 64).contiguous(), 1)
