@@ -741,18 +741,38 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     }
   };
 
+  // The wavefront's 64 rows and their scales for the write-out, one per lane (a coalesced load
+  // and a gather): asked for here, two dependent trips to memory ahead of the stage loop
+  // instead of behind it.
+  const float inv_scale = a.state->inv_scale;
+  const int my_row = a.grows[int64_t(g) * kRows + 2 * kSub * w + lane];
+  float my_dr = 1.0f, my_cr = 0.0f;
+  if (out < 0 && my_row >= 0) {
+    if (a.dinv_row != nullptr) my_dr = a.dinv_row[my_row];
+    if (a.corr != nullptr) my_cr = a.corr[my_row] * (a.dinv_col != nullptr ? a.dinv_col[my_row] : 1.0f);
+  }
+
   const bool dbg = (a.mode & 16) != 0;
   unsigned long long t_wait = 0, t_issue = 0, t_steps = 0, n_steps = 0;
   const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long wall_begin = dbg ? wall_clock64() : 0;   // 100 MHz, the same on every CU
   const int ns = s1 - s0;
+  // First steps of this wavefront's two sub-tiles in the stage about to run (the stage's own
+  // first step, the run of sub-tile 2 w, the run of sub-tile 2 w + 1, the end): read one stage
+  // ahead out of the step table that every stage's image carries, so that the first record of a
+  // stage can be asked for as soon as its barrier has fallen.
+  int cur_sf = 0, cur_h0 = 0, cur_h1 = 0, cur_h2 = 0;
   if (ns > 0) {   // the item's first stage: ids and step counts from global memory
     int col[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) col[b] = a.stage_col[int64_t(s0) * kStageCols + 16 * w + 4 * b + dma_row];
-    const int sf_first = __builtin_amdgcn_readfirstlane(a.step0[int64_t(s0) * kSubs]);
-    const int sf_second = __builtin_amdgcn_readfirstlane(a.step0[(int64_t(s0) + 1) * kSubs]);
-    issue(s0, col, sf_first, sf_second - sf_first);
+    const int32_t* st0 = a.step0 + int64_t(s0) * kSubs;
+    cur_sf = __builtin_amdgcn_readfirstlane(st0[0]);
+    cur_h0 = __builtin_amdgcn_readfirstlane(st0[2 * w]);
+    cur_h1 = __builtin_amdgcn_readfirstlane(st0[2 * w + 1]);
+    cur_h2 = __builtin_amdgcn_readfirstlane(st0[2 * w + 2]);
+    const int sf_second = __builtin_amdgcn_readfirstlane(st0[kSubs]);
+    issue(s0, col, cur_sf, sf_second - cur_sf);
   }
 
   for (int k = 0; k < ns; ++k) {
@@ -764,26 +784,13 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
 
     const uint32_t boff = kTableBytes + uint32_t(k & (kRing - 1)) * kStageBytes;
     const int* hdr = reinterpret_cast<const int*>(smem + boff + kStageRowsBytes + kSlotsBytes + kBitsBytes);
-    // The next stage is issued from the ids this stage's image carries, by every wavefront
-    // before its steps (taking turns between the two wavefronts of a SIMD, or spreading the
-    // issue between the steps, measured slower: the CU's memory pipeline takes ~1400 cycles
-    // to accept a stage either way and the earlier it starts the earlier the rows arrive).
-    auto issue_next = [&]() {
-      const int* nc = hdr + kHdrBytes / 4 + 16 * w + dma_row;
-      int col[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) col[b] = nc[4 * b];
-      const int nsf = __builtin_amdgcn_readfirstlane(hdr[kSubs]);
-      issue(s0 + k + 1, col, nsf, __builtin_amdgcn_readfirstlane(hdr[2 * kSubs]) - nsf);
-    };
-    if (k + 1 < ns) issue_next();
-    const int sf = __builtin_amdgcn_readfirstlane(hdr[0]);
-    const unsigned long long t2 = dbg ? __builtin_amdgcn_s_memtime() : 0;
     // this wavefront's steps of the stage: those of sub-tile 2 w, then those of sub-tile 2 w + 1,
     // one contiguous run of records
-    const int b0 = __builtin_amdgcn_readfirstlane(hdr[2 * w]) - sf;
-    const int n0 = __builtin_amdgcn_readfirstlane(hdr[2 * w + 1]) - sf - b0;
-    const int total = __builtin_amdgcn_readfirstlane(hdr[2 * w + 2]) - sf - b0;
+    const int b0 = cur_h0 - cur_sf;
+    const int n0 = cur_h1 - cur_sf - b0;
+    const int total = cur_h2 - cur_sf - b0;
+    const bool more = k + 1 < ns;
+    const bool steps_on = total > 0 && !(a.mode & 1);
     const uint32_t stage_lane = boff + lane_off;
     // A step's record as this lane needs it: the LDS offsets of the two rows it addresses in
     // the transposed reads, and its 8 row bits.  Reading past the wavefront's last record is
@@ -812,6 +819,60 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
       }
       return r;
     };
+    // Everything the stage needs out of LDS before its first MFMA is asked for in two rounds
+    // in front of the next stage's DMA instructions, whose issue (the CU's memory pipeline
+    // takes them at about one per 20 cycles, 72 of them per stage) then hides the second
+    // round: first the stage's first record together with the next stage's column ids and
+    // step counts, then the first step's pattern tile and tiles of X and the second record.
+    // Issued behind the DMA instructions, the three dependent round trips record -> pattern ->
+    // tiles stood between every barrier and the first MFMA of every wavefront.
+    u32x4 ahi, alo;                             // pattern tiles of the current step
+    uint32_t base_a = 0, base_b = 0;            // row addresses of the step whose tiles are being read
+    uint32_t offs = 0, bt = 0;                  // record of the step after that: both row offsets, row bits
+    uint32_t ta, tb;
+    h8 bh[NT], bl[NT];
+    if (steps_on) record(offs, bt);
+    int col[4] = {0, 0, 0, 0};
+    int nsf = 0, nsf2 = 0, nh0 = 0, nh1 = 0, nh2 = 0;
+    if (more) {
+      const int* nc = hdr + kHdrBytes / 4 + 16 * w + dma_row;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) col[b] = nc[4 * b];
+      nsf = hdr[kSubs];
+      nsf2 = hdr[2 * kSubs];
+      nh0 = hdr[kSubs + 2 * w];
+      nh1 = hdr[kSubs + 2 * w + 1];
+      nh2 = hdr[kSubs + 2 * w + 2];
+      // (taken to scalar registers here, with the first round: behind the second round the
+      // compiler would wait for all of it to land before the first DMA instruction)
+      nsf = __builtin_amdgcn_readfirstlane(nsf);
+      nsf2 = __builtin_amdgcn_readfirstlane(nsf2);
+      nh0 = __builtin_amdgcn_readfirstlane(nh0);
+      nh1 = __builtin_amdgcn_readfirstlane(nh1);
+      nh2 = __builtin_amdgcn_readfirstlane(nh2);
+    }
+    if (steps_on) {
+      ahi = pattern_hi((bt & 15u) << 3, (bt >> 1) & 0x78u);
+      base_a = stage_lane + (offs & 0xFFFFu);
+      base_b = stage_lane + (offs >> 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, nt);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, 4 + nt);
+      record(offs, bt);
+    }
+    // The next stage is issued from the ids this stage's image carries, by every wavefront
+    // before its steps (taking turns between the two wavefronts of a SIMD, or spreading the
+    // issue between the steps, measured slower: the CU's memory pipeline takes ~1400 cycles
+    // to accept a stage either way and the earlier it starts the earlier the rows arrive).
+    if (more) {
+      issue(s0 + k + 1, col, nsf, nsf2 - nsf);
+      cur_sf = nsf;
+      cur_h0 = nh0;
+      cur_h1 = nh1;
+      cur_h2 = nh2;
+    }
+    const unsigned long long t2 = dbg ? __builtin_amdgcn_s_memtime() : 0;
     // Software pipeline over the steps.  Behind every MFMA of step j the reads of the same tile
     // of X for step j + 1 go out into the registers that MFMA has just consumed, and behind the
     // last MFMA of a plane the pattern tile of step j + 1 for that plane; the record of step
@@ -820,22 +881,8 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     // a wavefront issues beside its MFMAs (an MFMA leaves room for about six).  One loop per
     // sub-tile, so that the accumulators are addressed statically; the prefetch runs across the
     // seam between the two lists and, harmlessly, one step past the end.
-    if (total > 0 && !(a.mode & 1)) {
-      u32x4 ahi, alo;                             // pattern tiles of the current step
-      uint32_t base_a, base_b;                    // row addresses of the step whose tiles are being read
-      uint32_t offs, bt;                          // record of the step after that: both row offsets, row bits
-      uint32_t ta, tb;
-      h8 bh[NT], bl[NT];
-      record(offs, bt);
-      ahi = pattern_hi((bt & 15u) << 3, (bt >> 1) & 0x78u);
+    if (steps_on) {
       alo = pattern_lo(ahi);
-      base_a = stage_lane + (offs & 0xFFFFu);
-      base_b = stage_lane + (offs >> 16);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, nt);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, 4 + nt);
-      record(offs, bt);
       auto body = [&](auto tt_tag) {
         constexpr int TT = decltype(tt_tag)::value;
         base_a = stage_lane + (offs & 0xFFFFu);
@@ -895,17 +942,10 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
   }
 
   // Accumulator register v of a lane: row (v & 3) + 8 (v >> 2) + 4 h of the sub-tile, feature
-  // lane & 31 of the N-tile.  The wavefront's 64 rows and their scales are looked up once, one
-  // per lane (a coalesced load and a gather), and handed out by v_readlane: looked up row by
-  // row, two dependent loads stood in front of every one of the 32 row pairs and writing the
-  // rows out took 40 us of a 380 us unit of work.
-  const float inv_scale = a.state->inv_scale;
-  const int my_row = a.grows[int64_t(g) * kRows + 2 * kSub * w + lane];
-  float my_dr = 1.0f, my_cr = 0.0f;
-  if (out < 0 && my_row >= 0) {
-    if (a.dinv_row != nullptr) my_dr = a.dinv_row[my_row];
-    if (a.corr != nullptr) my_cr = a.corr[my_row] * (a.dinv_col != nullptr ? a.dinv_col[my_row] : 1.0f);
-  }
+  // lane & 31 of the N-tile.  The wavefront's 64 rows and their scales, looked up once per lane
+  // before the stage loop, are handed out by v_readlane: looked up row by row, two dependent
+  // loads stood in front of every one of the 32 row pairs and writing the rows out took 40 us
+  // of a 380 us unit of work.
   auto pick = [&](int x, int src) {   // lane src (h = 0) or src + 4 (h = 1) of x; src is a constant
     const int lo = __builtin_amdgcn_readlane(x, src), hi = __builtin_amdgcn_readlane(x, src + 4);
     return h ? hi : lo;
