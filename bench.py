@@ -12,8 +12,9 @@ adjacency handle with X resident in HBM.  Rank 0 prints ONE JSON line.
 N = 1 also reports, outside the timed region and under keys of their own: the same
 step on the other benchmark shapes (hub-clipped and weight-2 Reddit, Reddit at F = 128,
 ogbn-products, R-MAT 10 M, PubMed), the CPU restatement of utils.py:81-96 on the SAME
-graph (median of 3 calls, checked against the GPU result), and one SGNN epoch at the
-reference's 10 000 optimiser iterations per layer run.
+graph (median of 3 calls, checked against the GPU result), and one SGNN epoch of the
+classification stack and one of the clustering (auto-encoder) stack at the reference's
+10 000 optimiser iterations per layer run.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU) splits the same job
 over the ranks (strong scaling).  The headline is always the pure row partition:
@@ -291,6 +292,42 @@ def sgnn_epoch(adj, X, device, max_iter, seed):
                 "share_of_first_forward_sweep": round(first_finish / t_first, 5)}}
 
 
+def sgnn_epoch_clustering(adj, X, device, max_iter, seed):
+    """The same two sweeps for the auto-encoder stack of the clustering task (GNN_tasks.py:325-356)
+    at the reference's Reddit clustering hyper-parameters (config.json, SGNN / Clustering /
+    Reddit: 128/64 neurons, relu, mask_rate 0.2, lr 1e-4, batch 512, eta 10, lam 1e-6): every
+    optimiser iteration samples a 512 x 512 block of the adjacency from the CSR on the GPU
+    (model/SGNN.py:167-175) and reconstructs it (model/SGNN.py:138-164)."""
+    import torch
+    from sgnn_amd.stacked import GAELayer, LayerParam, StackedGNN, get_activation
+    n, F = X.shape
+    model = StackedGNN.__new__(StackedGNN)
+    model.device, model.adjacency_tensor, model.content = device, adj, X
+    model.labels = model.training_mask = model.labels_host = model.metric_func = None
+    model.BP_count, model.eta = 1, 10
+    model.gnns, dim = [], F
+    for neurons in (128, 64):
+        p = LayerParam(neurons, inner_act=get_activation("relu"), act=get_activation("linear"),
+                       gnn_type=LayerParam.GAE, mask_rate=0.2, learning_rate=1e-4, max_iter=max_iter, lam=1e-6,
+                       batch_size=512)
+        model.gnns.append(GAELayer(adj, dim, neurons, p, device))
+        dim = neurons
+    torch.manual_seed(seed + 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inputs, _ = model._forward_sweep(False)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    model._backward_sweep(inputs)
+    model._forward_sweep(True)
+    torch.cuda.synchronize()
+    t_epoch = time.perf_counter() - t0
+    return {"task": "clustering, 2 auto-encoder layers (128, 64), batch 512, mask rate 0.2", "max_iter": max_iter,
+            "first_forward_sweep_s": t_first, "epoch_s": t_epoch, "optimiser_iterations": 4 * max_iter,
+            "s_per_iteration": t_epoch / (4 * max_iter)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -475,7 +512,7 @@ def main():
     wall, ev_ms, k_ms, k_n = timed_steps(step, args.steps, args.warmup, device, world, dist if world > 1 else None)
 
     copy_gbps = None
-    epoch = None
+    epoch = epoch_gae = None
     others = []
     cpu = None
     if rank == 0 and world == 1:
@@ -500,6 +537,11 @@ def main():
                 epoch = sgnn_epoch(adj, X, device, args.epoch_iters, args.seed)
             except Exception as exc:                  # the SpMM line must come out whatever happens here
                 epoch = {"error": f"{type(exc).__name__}: {exc}"}
+            log(f"SGNN clustering epoch at {args.epoch_iters} iterations per layer run")
+            try:
+                epoch_gae = sgnn_epoch_clustering(adj, X, device, args.epoch_iters, args.seed)
+            except Exception as exc:
+                epoch_gae = {"error": f"{type(exc).__name__}: {exc}"}
         if args.workload == "reddit" and args.max_degree is None and args.weight is None and not args.no_extras:
             del adj, X
             torch.cuda.empty_cache()
@@ -580,6 +622,8 @@ def main():
             roof["fabric_GBps"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9
         if epoch:
             out["sgnn_epoch"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in epoch.items()}
+        if epoch_gae:
+            out["sgnn_epoch_clustering"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in epoch_gae.items()}
         if others:
             out["other_workloads"] = others
         if cpu:
