@@ -653,7 +653,7 @@ __device__ __forceinline__ __attribute__((address_space(3))) T* lds(uint32_t off
 // NT = the slice's N-tiles of 32 features that hold features below F (the last slice of a
 // width that is not a multiple of 128, every slice of a narrow one): the tiles beyond are
 // fetched with the row but neither read from LDS nor multiplied.
-template <int NT>
+template <int NT, bool DIAG>
 __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const int slice, const int work) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned long long wall_entry = (a.mode & 16) ? wall_clock64() : 0;
@@ -744,12 +744,12 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
   // The wavefront's 64 rows and their scales for the write-out, one per lane (a coalesced load
   // and a gather): asked for here, two dependent trips to memory ahead of the stage loop
   // instead of behind it.
-  const float inv_scale = a.state->inv_scale;
+  const float inv_scale_v = a.state->inv_scale;
   const int my_row = a.grows[int64_t(g) * kRows + 2 * kSub * w + lane];
   float my_dr = 1.0f, my_cr = 0.0f;
   if (out < 0 && my_row >= 0) {
     if (a.dinv_row != nullptr) my_dr = a.dinv_row[my_row];
-    if (a.corr != nullptr) my_cr = a.corr[my_row] * (a.dinv_col != nullptr ? a.dinv_col[my_row] : 1.0f);
+    if (DIAG) my_cr = a.corr[my_row] * (a.dinv_col != nullptr ? a.dinv_col[my_row] : 1.0f);
   }
 
   const bool dbg = (a.mode & 16) != 0;
@@ -946,6 +946,16 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
   // before the stage loop, are handed out by v_readlane: looked up row by row, two dependent
   // loads stood in front of every one of the 32 row pairs and writing the rows out took 40 us
   // of a 380 us unit of work.
+  // The three values came from memory; the unrolled write-out below reads them through
+  // v_readlane in many basic blocks, and the compiler, unable to prove across the branches that
+  // the loads have landed, put a wait for ALL outstanding memory operations in front of every
+  // row: every row waited for the stores of the row before to be acknowledged (22 us per unit
+  // of work).  Copied once through a register move they are plain register values.
+  const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, inv_scale_v)));   // (the same holds for the scale)
+  int row_v, dr_v, cr_v;
+  asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+               : "=&v"(row_v), "=&v"(dr_v), "=&v"(cr_v)
+               : "v"(my_row), "v"(__builtin_bit_cast(int, my_dr)), "v"(__builtin_bit_cast(int, my_cr)));
   auto pick = [&](int x, int src) {   // lane src (h = 0) or src + 4 (h = 1) of x; src is a constant
     const int lo = __builtin_amdgcn_readlane(x, src), hi = __builtin_amdgcn_readlane(x, src + 4);
     return h ? hi : lo;
@@ -954,21 +964,36 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int t = 2 * w + tt;
+    // Diagonal correction: the sub-tile's own elements of X, all 16 rows' worth asked for in one
+    // go and without a branch around any load (a row that does not exist reads row 0, a feature
+    // past F reads the last one; neither value is used), so that one wait covers them; loaded
+    // where they are used, every element stood behind a wait for everything outstanding.
+    const bool diag = DIAG && out < 0;   // uniform (DIAG: the launch has a diagonal correction)
+    [[maybe_unused]] float xq[DIAG ? 16 : 1][NT];
+    if constexpr (DIAG) if (diag) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = max(pick(row_v, kSub * tt + (v & 3) + 8 * (v >> 2)), 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          xq[v][nt] = a.X[int64_t(row) * a.ldx + min(slice * kSlice + nt * 32 + (lane & 31), a.F - 1)];
+      }
+    }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int src = kSub * tt + (v & 3) + 8 * (v >> 2);
       const int rr = kSub * t + (v & 3) + 8 * (v >> 2) + 4 * h;
-      const int row = pick(my_row, src);
+      const int row = pick(row_v, src);
       if (row < 0) continue;
-      const float dr = __builtin_bit_cast(float, pick(__builtin_bit_cast(int, my_dr), src));
-      const float cr = __builtin_bit_cast(float, pick(__builtin_bit_cast(int, my_cr), src));
+      const float dr = __builtin_bit_cast(float, pick(dr_v, src));
+      const float cr = __builtin_bit_cast(float, pick(cr_v, src));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int f = slice * kSlice + nt * 32 + (lane & 31);
         float y = acc[tt][nt][v] * inv_scale;   // exact: a power of two
         if (out < 0) {
           if (f >= a.F) continue;
-          if (a.corr != nullptr) y = fmaf(a.w_off, y, cr * a.X[int64_t(row) * a.ldx + f]);
+          if constexpr (DIAG) y = fmaf(a.w_off, y, cr * xq[v][nt]);
           else if (a.w_off != 1.0f) y *= a.w_off;
           if (a.dinv_row != nullptr) {
             y = y * dr;
@@ -1012,10 +1037,17 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     if (b >= total) break;
     const int slice = b / a.items, item = b - slice * a.items;
     const int tiles = (min(kSlice, a.F - slice * kSlice) + 31) / 32;   // workgroup-uniform
-    if (tiles >= 4) tg_run<4>(a, item, slice, b);
-    else if (tiles == 3) tg_run<3>(a, item, slice, b);
-    else if (tiles == 2) tg_run<2>(a, item, slice, b);
-    else tg_run<1>(a, item, slice, b);
+    if (a.corr != nullptr) {   // the same for every unit of the launch
+      if (tiles >= 4) tg_run<4, true>(a, item, slice, b);
+      else if (tiles == 3) tg_run<3, true>(a, item, slice, b);
+      else if (tiles == 2) tg_run<2, true>(a, item, slice, b);
+      else tg_run<1, true>(a, item, slice, b);
+    } else {
+      if (tiles >= 4) tg_run<4, false>(a, item, slice, b);
+      else if (tiles == 3) tg_run<3, false>(a, item, slice, b);
+      else if (tiles == 2) tg_run<2, false>(a, item, slice, b);
+      else tg_run<1, false>(a, item, slice, b);
+    }
     if (a.mode & 128) break;   // diagnostics: one workgroup per (item, slice) pair
   }
 }

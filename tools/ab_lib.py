@@ -4,6 +4,7 @@ through the library file named on the command line, relative to the repository r
 Build the variants on the CPU (`hipcc` as `__graft_entry__.build` does), drop them next to the
 sources as e.g. ab_old.so / ab_new.so, and alternate:
     for v in old new old new; do python tools/ab_lib.py ab_$v.so; done
+A second argument gives every off-diagonal entry that weight (2: Reddit's A + A^T).
 (delete the files afterwards: every GPU call uploads the tree)."""
 import os
 import sys
@@ -19,8 +20,9 @@ from sgnn_amd.graphgen import SHAPES, rmat_undirected_device
 dev = torch.device("cuda:0")
 n, E, F = SHAPES["reddit"]
 row, col = rmat_undirected_device(n, E, seed=1, device=dev)
-adj = NormAdj.from_coo(row, col, None, n, dev)
-del row, col
+val = torch.full((row.numel(),), float(sys.argv[2]), device=dev) if len(sys.argv) > 2 else None
+adj = NormAdj.from_coo(row, col, val, n, dev)
+del row, col, val
 X = torch.randn(n, F, device=dev)
 lib = _lib.load()
 for _ in range(5):
