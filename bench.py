@@ -620,6 +620,9 @@ def main():
             roof["frac_of_copy"] = achieved / copy_gbps
         if roof["traffic"]:                                   # bytes the L2s fetched or wrote, per launch
             roof["fabric_GBps"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9
+            # bytes actually moved over the L2's fabric side (Infinity-Cache hits included) over the vendor
+            # peak: the "measured bytes" fraction, stated beside `frac`, which prices algorithmic bytes
+            roof["fabric_frac_of_peak"] = roof["fabric_GBps"] / HBM_PEAK_GBPS
         if epoch:
             out["sgnn_epoch"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in epoch.items()}
         if epoch_gae:
