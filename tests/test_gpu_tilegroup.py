@@ -64,6 +64,26 @@ def test_tilegroup_weight2_and_single_hop_entry(gpu_device):
     assert float((Y - Y_ref).norm() / Y_ref.norm()) <= TOL
 
 
+@pytest.mark.parametrize("F", [16, 37, 48, 96, 601, 602])
+def test_tilegroup_weight2_every_last_slice_width(gpu_device, F):
+    """Weight 2 off the diagonal, 1 on it: the kernel instances with the diagonal correction, with
+    last slices of one to four N-tiles and widths that end inside a tile (the correction's reads
+    of X are clamped to the row there), on a node count that leaves a group partly empty."""
+    n = 2300
+    adj, r, c, v = _graph(n, 50_000, seed=F, dev=gpu_device, weight=2.0)
+    assert adj.w_off == 2.0 and adj.corr is not None
+    rowptr, colidx, vals, deg, dinv = orc.norm_csr(r, c, v, n)
+    X = np.random.default_rng(F + 1).standard_normal((n, F)).astype(np.float32)
+    exp = orc.spmm_csr(rowptr, colidx, vals, dinv, dinv, X)
+    # X in a buffer of its own that ends with its last row: the clamped reads stay inside it
+    Xd = torch.empty(n * F, device=gpu_device)
+    Xd.copy_(torch.from_numpy(X).reshape(-1))
+    Y = adj.propagate(Xd.view(n, F), 1).cpu().numpy()
+    assert adj._tg and int(adj._tg_bufs[F]["state"][1].item()) == 0
+    assert rel_err(Y, exp) <= TOL
+    assert scaled_err(Y, exp, abs_scale(rowptr, colidx, vals, dinv, dinv, X, 1)) <= TOL
+
+
 def test_tilegroup_wide_range_and_nonfinite_fall_back(gpu_device):
     adj, r, c, v = _graph(3000, 50_000, seed=9, dev=gpu_device)
     F = 128
