@@ -57,6 +57,7 @@ constexpr int kSlotBits = 7;                     // log2(kStageCols)
 constexpr int kStepCols = 16;                    // K of one MFMA
 constexpr int kSlice = 128;                      // features of a slice (4 MFMA N-tiles)
 constexpr int kWaves = 8;
+constexpr int kEarlyRows = 2;                    // row DMA instructions of a wavefront issued ahead of the stage's first tile reads (4 and 8 measured 1 % slower)
 constexpr int kRing = 2;                         // stages resident in LDS: one being read, one arriving
 constexpr int kRowBytes = 512;                   // one node's slice: hi 256 B | lo 256 B
 constexpr int kStageRowsBytes = kStageCols * kRowBytes;
@@ -706,12 +707,14 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
   // the stage has steps), the first-step table from this stage on, and the column ids of the
   // following stages, so that the next stage is issued from LDS and not from scalar loads
   // whose latency every wavefront would sit out once per stage.
-  auto issue = [&](int s, const int (&col)[4], int sf32, int steps) {
+  auto issue_rows = [&](int s, const int (&col)[4], auto lo_tag, auto hi_tag) {   // row instructions lo .. hi - 1 of the wavefront's eight
+    constexpr int lo = decltype(lo_tag)::value, hi = decltype(hi_tag)::value;
     const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
     // (lanes whose N-tile holds no feature below F fetch nothing: lane l moves segment l >> 4)
     if (!(a.mode & 2) && (lane >> 4) < NT) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        if (i < lo || i >= hi) continue;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(8 * w + i) * 1024u);
         const uint32_t off = src_off + uint32_t(i & 1) * 256u;
         const int c = (a.mode & 64) ? (col[i >> 1] & 4095) : col[i >> 1];   // diagnostics: every fetch an L2 hit
@@ -719,6 +722,9 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
         else tg_dma16(xs + int64_t(c) * kRowBytes + off, dst);
       }
     }
+  };
+  auto issue_records = [&](int s, int sf32, int steps) {
+    const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
     const int64_t sf = sf32;
     const uint32_t rec = buf + kStageRowsBytes;
     if (w >= 6) {
@@ -739,6 +745,10 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
       tg_dma16(a.stage_col + (int64_t(s) + 1) * kStageCols + lane * 4,
                __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + kBitsBytes + kHdrBytes));
     }
+  };
+  auto issue = [&](int s, const int (&col)[4], int sf32, int steps) {
+    issue_rows(s, col, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+    issue_records(s, sf32, steps);
   };
 
   // The wavefront's 64 rows and their scales for the write-out, one per lane (a coalesced load
@@ -851,6 +861,10 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
       nh1 = __builtin_amdgcn_readfirstlane(nh1);
       nh2 = __builtin_amdgcn_readfirstlane(nh2);
     }
+    // (the first row instructions go out ahead of the second round: the barrier at the end of
+    // the stage waits for the last row to land, and the CU's memory pipeline, once started,
+    // works through the stage's instructions back to back)
+    if (more) issue_rows(s0 + k + 1, col, std::integral_constant<int, 0>{}, std::integral_constant<int, kEarlyRows>{});
     if (steps_on) {
       ahi = pattern_hi((bt & 15u) << 3, (bt >> 1) & 0x78u);
       base_a = stage_lane + (offs & 0xFFFFu);
@@ -866,7 +880,8 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     // issue between the steps, measured slower: the CU's memory pipeline takes ~1400 cycles
     // to accept a stage either way and the earlier it starts the earlier the rows arrive).
     if (more) {
-      issue(s0 + k + 1, col, nsf, nsf2 - nsf);
+      issue_rows(s0 + k + 1, col, std::integral_constant<int, kEarlyRows>{}, std::integral_constant<int, 8>{});
+      issue_records(s0 + k + 1, nsf, nsf2 - nsf);
       cur_sf = nsf;
       cur_h0 = nh0;
       cur_h1 = nh1;
