@@ -97,11 +97,15 @@ def timed_steps(step, steps, warmup, device, world=1, dist=None):
     return wall, ev0.elapsed_time(ev1) / steps, (k_ms / k_n if k_n else None), k_n
 
 
-def load_traffic(key):
-    """HBM bytes per launch of the main SpMM kernel from the committed PMC profile, if one matches."""
+def load_traffic(key, kernel=None):
+    """HBM bytes per launch of the main SpMM kernel from the committed PMC profile, if there is
+    one for this workload taken with the kernel that ran."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return float(json.load(f)[key]["hbm_fabric_bytes"])
+            rec = json.load(f)[key]
+        if kernel is not None and rec.get("kernel") not in (None, kernel):
+            return None
+        return float(rec["hbm_fabric_bytes"])
     except Exception:
         return None
 
@@ -154,7 +158,7 @@ def sub_record(workload, seed, device, max_degree=None, weight=None, min_region_
            "value": adj.nnz * F / (wall / steps), "algorithmic_bytes": b_alg,
            "frac": b_alg / ((k_ms or ev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "frac_whole_step": b_alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-           "traffic": load_traffic(key), "adjacency_build_ms": round(t_build * 1e3, 1)}
+           "traffic": load_traffic(key, main), "adjacency_build_ms": round(t_build * 1e3, 1)}
     if wall / steps < 0.5e-3:
         # a hop this short is bound by the host's launch calls: the same launches replayed from a
         # HIP graph (how the SGNN stack runs its inner loops) give the device-side figure
@@ -603,7 +607,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": load_traffic(key) if world == 1 else None,
+                "traffic": load_traffic(key, main_kernel) if world == 1 else None,
                 "algorithmic_bytes": b_alg,
                 "kernel_ms": kernel_ms,                       # HIP events around every launch of the main kernel
                 "kernel_launches_timed": k_n,

@@ -56,8 +56,10 @@ def weight_structure(n, rowptr, colidx, vals):
 
 
 # a fetched row of X must serve at least this many stored entries, on average over the
-# groups of 512 rows, for the tile-group kernel to be chosen automatically
-TILEGROUP_MIN_SHARING = 4.0
+# groups of 512 rows, for the tile-group kernel to be chosen automatically (the ogbn-products
+# shape, at 2.35, takes 5.66 ms per hop on it against 6.05 ms on the row-group kernel; R-MAT
+# with 10^7 nodes, at 1.06, shares nothing)
+TILEGROUP_MIN_SHARING = 2.25
 
 
 def tilegroup_build(n_rows, n_cols, nnz, rowptr, colidx, device, auto=True):
