@@ -461,12 +461,17 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, const fl
   // a workgroup walks whole rows, four at a time so that four loads are in flight per lane
   // (lanes along the features, 8-byte loads where the row allows)
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
-  for (int64_t r0 = 4 * int64_t(blockIdx.x); r0 < n; r0 += 4 * int64_t(gridDim.x)) {
+  // A narrow row does not fill the workgroup: `lanes_row` threads (whole wavefronts) take a row
+  // and the workgroup walks blockDim / lanes_row quadruples of rows side by side.
+  const int per_row = pairs ? int((F + 1) / 2) : int(F);
+  const int lanes_row = per_row >= int(blockDim.x) ? int(blockDim.x) : (per_row + kWave - 1) / kWave * kWave;
+  const int subs = int(blockDim.x) / lanes_row, sub = int(threadIdx.x) / lanes_row, tin = int(threadIdx.x) % lanes_row;
+  for (int64_t r0 = 4 * (int64_t(blockIdx.x) * subs + sub); sub < subs && r0 < n; r0 += 4 * int64_t(gridDim.x) * subs) {
     float sr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sr[i] = (r0 + i < n) ? (scale_row ? scale_row[r0 + i] : 1.0f) : 0.0f;
     if (pairs) {
-      for (int64_t f = 2 * int64_t(threadIdx.x); f < F; f += 2 * int64_t(blockDim.x)) {
+      for (int64_t f = 2 * int64_t(tin); f < F; f += 2 * int64_t(lanes_row)) {
         float2 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, const fl
       }
     } else {
       for (int i = 0; i < 4 && r0 + i < n; ++i)
-        for (int64_t f = threadIdx.x; f < F; f += blockDim.x) {
+        for (int64_t f = tin; f < F; f += lanes_row) {
           const uint32_t b0 = __builtin_bit_cast(uint32_t, X[(r0 + i) * ldx + f] * sr[i]) & 0x7FFFFFFFu;
           m = b0 > m ? b0 : m;
         }
@@ -535,11 +540,16 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
   const int64_t Fpad = n_slices * kSlice;
   bool bad = false;
   uint32_t tiny = 0;
-  // (one node per pass: the 4-byte stores bound this kernel, more loads in flight do not help)
-  for (int64_t node = blockIdx.x; node < n; node += gridDim.x) {
+  // (one node per pass and set of threads: the 4-byte stores bound this kernel, more loads in
+  // flight do not help; a node of one or two slices needs 64 or 128 threads, so the workgroup
+  // takes blockDim / that many nodes side by side)
+  const int per_node = int(Fpad / 2);
+  const int lanes_node = per_node >= int(blockDim.x) ? int(blockDim.x) : per_node;   // a multiple of 64
+  const int subs = int(blockDim.x) / lanes_node, sub = int(threadIdx.x) / lanes_node, tin = int(threadIdx.x) % lanes_node;
+  for (int64_t node = int64_t(blockIdx.x) * subs + sub; sub < subs && node < n; node += int64_t(gridDim.x) * subs) {
     const float sr = scale_row ? scale_row[node] : 1.0f;
     const float* row = X + node * ldx;
-    for (int64_t f = 2 * int64_t(threadIdx.x); f < Fpad; f += 2 * int64_t(blockDim.x)) {
+    for (int64_t f = 2 * int64_t(tin); f < Fpad; f += 2 * int64_t(lanes_node)) {
       float x[2] = {0.0f, 0.0f};
       if (f + 1 < F && pairs) {
         const float2 v = *reinterpret_cast<const float2*>(row + f);
@@ -1300,7 +1310,7 @@ int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, 
   HIP_TRY(hipMemsetAsync(s, 0, sizeof(TgState), st));
   // a thread per pair of features of a row: as many wavefronts as a row (padded to whole slices) needs
   const int64_t pairs = slices * kSlice / 2;
-  const unsigned T = unsigned(pairs >= 1024 ? 1024 : (pairs + kWave - 1) / kWave * kWave);
+  const unsigned T = unsigned(pairs >= 1024 ? 1024 : (pairs <= 256 ? 256 : (pairs + kWave - 1) / kWave * kWave));
   const unsigned row_blocks = unsigned(n_cols < 16384 ? n_cols : 16384);
   hipLaunchKernelGGL(k_tg_amax, dim3(row_blocks < 2048 ? row_blocks : 2048), dim3(T), 0, st, n_cols, F, scale_row, X, ldx, s);
   HIP_TRY(hipGetLastError());
