@@ -48,7 +48,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .norm_adj import NormAdj, tilegroup_build, tilegroup_hop
+from .norm_adj import TILEGROUP_MIN_NNZ, NormAdj, tilegroup_build, tilegroup_hop
 
 
 def grid_layout(rank, world, feature_groups, F, align=2):
@@ -447,7 +447,7 @@ class _LocalBlock:
         if self.use_tilegroup is False or a.nnz == 0 or a.w_off is None or a.corr is not None:
             return None        # (a diagonal of its own would need the block's rows of X at an offset)
         auto = self.use_tilegroup is None
-        if auto and (F < 16 or self.n_rows < 8192 or a.nnz < 32 * self.n_rows):
+        if auto and (F < 16 or a.nnz < TILEGROUP_MIN_NNZ):     # the rule of NormAdj._tilegroup_plan, on the rank's block
             return None
         if self._tg is None:
             self._tg = tilegroup_build(self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a.device, auto)

@@ -55,11 +55,15 @@ def weight_structure(n, rowptr, colidx, vals):
     return False, w, corr
 
 
-# a fetched row of X must serve at least this many stored entries, on average over the
-# groups of 512 rows, for the tile-group kernel to be chosen automatically (the ogbn-products
-# shape, at 2.35, takes 5.66 ms per hop on it against 6.05 ms on the row-group kernel; R-MAT
-# with 10^7 nodes, at 1.06, shares nothing)
-TILEGROUP_MIN_SHARING = 2.25
+# When the tile-group kernel is chosen automatically (tools/policy_probe.py, one hop against
+# the row-group / plain kernels on R-MAT graphs): it needs enough stages of 128 merged columns
+# to keep 256 CUs busy -- with 1.7 M and 2.5 M stored entries it is 1.36 and 1.08 times slower,
+# with 6.5 M and more 0.75 to 0.95 times as long -- and then pays from little sharing on (stored
+# entries per fetched row, on average over the groups of 512 rows): R-MAT with 10^7 nodes, at
+# 1.6, takes 15.5 ms per hop on it against 19.2 ms, the ogbn-products shape, at 2.35, 5.05
+# against 6.05 ms, the Reddit shape, at 9.5, 5.2 against 10.1 ms.
+TILEGROUP_MIN_SHARING = 1.5
+TILEGROUP_MIN_NNZ = 4_000_000
 
 
 def tilegroup_build(n_rows, n_cols, nnz, rowptr, colidx, device, auto=True):
@@ -309,7 +313,7 @@ class NormAdj:
         if self.w_off is None:
             return None
         auto = self.use_tilegroup is None
-        if auto and (F < 16 or self.n < 8192 or self.nnz < 32 * self.n):
+        if auto and (F < 16 or self.nnz < TILEGROUP_MIN_NNZ):
             return None
         if self._tg is None:
             self._tg = tilegroup_build(self.n, self.n, self.nnz, self.rowptr, self.colidx, self.device, auto)

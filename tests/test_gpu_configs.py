@@ -107,7 +107,7 @@ def test_rmat10m_shape_full_size_properties(gpu_device):
     g = torch.Generator(device=dev); g.manual_seed(4)
     X = torch.randn(n, F, device=dev, generator=g)
     assert X.numel() * 4 > (1 << 32)              # the operand needs 64-bit row addressing
-    adj.use_rowgroup = True
+    adj.use_rowgroup, adj.use_tilegroup = True, False     # (left to itself the handle takes the tile-group kernel: below)
     Y_rg = adj.propagate(X, 1)
     assert adj._plans, "row-group plan was not used"
     adj.use_rowgroup = False
@@ -118,11 +118,10 @@ def test_rmat10m_shape_full_size_properties(gpu_device):
     some = scale > 0                  # 1.3e9 normal draws hold a few exact zeros (isolated nodes keep them)
     assert float(diff[~some].sum()) == 0.0
     assert float((diff[some] / scale[some]).max()) <= TOL
-    # The tile-group kernel does not pay on this graph (its rows share almost no columns) and is
-    # not chosen for it, but forced it must still be right: with 10^7 nodes a feature slice of
-    # the operand planes spans 5.1 GB, the only case in which that kernel addresses the rows it
-    # fetches with 64-bit offsets.
-    adj.use_rowgroup, adj.use_tilegroup = True, True
+    # The tile-group kernel, which the handle picks for this graph by itself (1.6 stored entries
+    # per fetched row): with 10^7 nodes a feature slice of the operand planes spans 5.1 GB, the
+    # only case in which that kernel addresses the rows it fetches with 64-bit offsets.
+    adj.use_rowgroup, adj.use_tilegroup = True, None
     Y_tg = adj.propagate(X, 1)
     assert adj._tg, "tile-group plan was not used"
     assert n * 512 > (1 << 32)
@@ -130,10 +129,8 @@ def test_rmat10m_shape_full_size_properties(gpu_device):
     diff = (Y_tg - Y_csr).abs()
     assert float(diff[~some].sum()) == 0.0
     assert float((diff[some] / scale[some]).max()) <= TOL
-    adj.use_tilegroup = None
-    adj._tg, adj._tg_bufs = None, {}
     del Y_csr, Y_tg, scale, diff, some
-    adj.use_rowgroup = True
+    # the identities below on the kernel the handle picks
     s = adj.deg.sqrt()
     fixed = adj.propagate(s[:, None].expand(n, 64).contiguous(), 1)
     assert float(((fixed - s[:, None]).abs() / s[:, None]).max()) <= TOL

@@ -100,13 +100,13 @@ def _tg_worker(rank, world, port, n, E, F, order, slices, q):
 
 @pytest.mark.parametrize("slices", [1, 2])
 def test_two_ranks_take_the_tile_group_kernel_on_a_dense_enough_graph(gpu_device, slices):
-    """40 000 nodes, average degree ~300: each rank's 20 000 rows pass the sharing test, so the
+    """40 000 nodes, average degree ~250, 5 M stored entries per rank: each rank's 20 000 rows pass the size and sharing tests, so the
     rank-local multiply is the matrix-core kernel on the gathered (pre-scaled) operand."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tg_worker, args=(k, world, port, 40_000, 6_000_000, 200, 2, slices, q)) for k in range(world)]
+    procs = [ctx.Process(target=_tg_worker, args=(k, world, port, 40_000, 10_000_000, 200, 2, slices, q)) for k in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]

@@ -91,7 +91,7 @@ def test_x_larger_than_4gib(gpu_device, rowgroup):
     n, F, ld = 300_000, 64, 4096
     row, col = rmat_undirected_device(n, 6_000_000, seed=2, device=dev)
     adj = NormAdj.from_coo(row, col, None, n, dev)
-    adj.use_rowgroup = rowgroup
+    adj.use_rowgroup, adj.use_tilegroup = rowgroup, False      # the two kernels that read X in place
     big = torch.zeros(n, ld, device=dev)
     assert big.numel() * 4 > (1 << 32)
     g = torch.Generator(device=dev); g.manual_seed(5)
