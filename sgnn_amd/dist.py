@@ -50,6 +50,8 @@ import torch.distributed as dist
 from . import _lib
 from .norm_adj import TILEGROUP_MIN_NNZ, NormAdj, tilegroup_build, tilegroup_hop
 
+TILEGROUP_MIN_ENTRIES_PER_OPERAND_ROW = 40
+
 
 def grid_layout(rank, world, feature_groups, F, align=2):
     """Place ``rank`` on a ``feature_groups`` x ``world // feature_groups`` grid:
@@ -448,6 +450,13 @@ class _LocalBlock:
             return None        # (a diagonal of its own would need the block's rows of X at an offset)
         auto = self.use_tilegroup is None
         if auto and (F < 16 or a.nnz < TILEGROUP_MIN_NNZ):     # the rule of NormAdj._tilegroup_plan, on the rank's block
+            return None
+        # A rank splits the whole operand it multiplies with (its own rows and everyone else's) but
+        # multiplies only its own rows' entries: per node of the operand the max and split passes cost
+        # what about 40 stored entries save against the row-group kernel (one GPU, per entry and
+        # node: Reddit shape 44 ps saved, 2.2 ns spent; products 12 ps, 0.45 ns; R-MAT 10 M 25 ps,
+        # 0.41 ns), so a block thinner than that stays on the row-group kernel.
+        if auto and a.nnz < TILEGROUP_MIN_ENTRIES_PER_OPERAND_ROW * self.n_cols:
             return None
         if self._tg is None:
             self._tg = tilegroup_build(self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a.device, auto)
