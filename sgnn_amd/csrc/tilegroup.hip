@@ -938,12 +938,15 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
       // the arbitration (oldest first) lets the first wavefront through its steps in 0.86 of the
       // mean time and the second in 1.14; raised, the figures swap, and the hop is 1.2 % shorter
       // (the wavefront that is slow in its steps is then the one that was first through the
-      // issue of the next stage).  Priority on for the whole stage loop: half of that.
+      // issue of the next stage).  Priority on for the whole stage loop: half of that.  The two
+      // swap at the seam between the sub-tile loops (the first wavefront raised in its second
+      // loop): another 0.4 %.
       const bool second = w >= kWaves / 2;
       if (second) __builtin_amdgcn_s_setprio(1);
       for (; j < n0; ++j) body(std::integral_constant<int, 0>{});
+      if (second) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
       for (; j < total; ++j) body(std::integral_constant<int, 1>{});
-      if (second) __builtin_amdgcn_s_setprio(0);
+      if (!second) __builtin_amdgcn_s_setprio(0);
     }
     if (dbg) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
