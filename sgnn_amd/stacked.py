@@ -518,18 +518,37 @@ class _Layer(torch.nn.Module):
         return embedding
 
 
-def _mask_to_rows(mask, device):
+def _mask_to_rows(mask, device, n=None):
     """Node ids a training mask selects.  The reference fancy-indexes with the mask
     (model/SGNN.py:412-415), which takes a boolean mask (Planetoid loaders) as well as an
-    index array (data_loader.py:133 passes ``train_index`` for the OGB graphs)."""
+    index array (data_loader.py:133 passes ``train_index`` for the OGB graphs).  With ``n``
+    (the number of nodes) the selection is checked as that indexing checks it: a boolean mask
+    must have ``n`` entries, negative ids count from the end, ids outside ``[-n, n)`` raise
+    ``IndexError``; an empty selection raises ``ValueError`` (the reference would fail later, in
+    ``randperm(0)[:batch]`` feeding a mean over no rows).  The ids go to the kernels as raw row
+    numbers, so nothing unchecked may pass here."""
     mask = torch.as_tensor(mask).to(device)
     if mask.dtype in (torch.bool, torch.uint8):          # torch indexes with a byte tensor as with a mask
-        return torch.nonzero(mask).squeeze(1)
-    if mask.dtype in (torch.int64, torch.int32, torch.int16, torch.int8):
+        if mask.dim() != 1:
+            raise ValueError("a boolean training mask must be 1-D")
+        if n is not None and mask.numel() != n:
+            raise IndexError(f"boolean training mask has {mask.numel()} entries for {n} nodes")
+        rows = torch.nonzero(mask).squeeze(1)
+    elif mask.dtype in (torch.int64, torch.int32, torch.int16, torch.int8):
         if mask.dim() != 1:
             raise ValueError("an index-array mask must be 1-D")
-        return mask.long().contiguous()
-    raise TypeError(f"training mask must be boolean or an integer index array, got {mask.dtype}")
+        rows = mask.long().contiguous()
+        if n is not None and rows.numel() > 0:
+            lo, hi = int(rows.min().item()), int(rows.max().item())
+            if lo < -n or hi >= n:
+                raise IndexError(f"training index {lo if lo < -n else hi} is out of bounds for {n} nodes")
+            if lo < 0:
+                rows = torch.where(rows < 0, rows + n, rows)
+    else:
+        raise TypeError(f"training mask must be boolean or an integer index array, got {mask.dtype}")
+    if n is not None and rows.numel() == 0:
+        raise ValueError("the training mask selects no node")
+    return rows
 
 
 class EmbeddingLayer(_Layer):
@@ -546,7 +565,7 @@ class EmbeddingLayer(_Layer):
             # The reference samples rows of processed_X[mask] (model/SGNN.py:412-421); here the
             # drawn positions are mapped to node ids instead, so every batch reads PX, the labels
             # and the target directly and no masked copies are made.
-            train_rows = _mask_to_rows(self.train_mask, self.device)
+            train_rows = _mask_to_rows(self.train_mask, self.device, PX.shape[0])
             n_train, n_all = train_rows.numel(), PX.shape[0]
             b1, b2 = min(self.batch_size, n_train), min(self.batch_size, n_all)
 
