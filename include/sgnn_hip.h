@@ -192,13 +192,19 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
 /*
  * Tile-group SpMM: the adj.mm of utils.py:94 with its row scalings (utils.py:93, 95) for
  * pattern-only adjacencies (all stored off-diagonal values equal) whose rows share many
- * columns — the Reddit shape.  Groups of 512 degree-ranked rows share every fetched row of
+ * columns -- the Reddit shape.  Groups of 512 degree-ranked rows share every fetched row of
  * X through LDS; the sums run on the matrix cores (v_mfma_f32_32x32x16_f16, fp32
- * accumulation) over X split into two fp16 planes that together reproduce every fp32 input
- * to 2^-22 relative or better.  Results agree with sgnn_spmm_csr_f32 to fp32 rounding
- * (different summation order), are reproducible run to run, and inputs the planes cannot
- * represent (non-finite values, dynamic range beyond 2^28) are detected on the device and
- * computed by the plain CSR kernel instead, with no host synchronisation.
+ * accumulation) over X split into two fp16 planes, hi + lo / 2048, with one power-of-two
+ * scale per feature column (columns never mix in A . X).  What the planes do to the
+ * arithmetic, as enforced on the device: every element is reproduced to 2^-21 relative or
+ * better (checked element by element when the planes are written; typically 2^-22); an
+ * operand with a non-finite element, an element the planes miss by more, or more than
+ * max(16, elements / 2^20) nonzero elements so far below their column's largest magnitude
+ * (2^-33) that fewer than 17 of their bits survive, is refused: a device flag goes up, the
+ * matrix-core kernel does nothing, and the plain CSR kernel launched behind it computes the
+ * result from the fp32 operand (bit-identical to sgnn_spmm_csr_f32), with no host
+ * synchronisation.  Accepted operands give results that agree with sgnn_spmm_csr_f32 to
+ * 2^-20 of |A||X| element by element (summation order included) and are reproducible run to run.
  *
  * Plan (once per matrix), two steps because its size depends on the matrix:
  *   sgnn_tilegroup_analyze  sorts and counts into `workspace`
@@ -207,34 +213,67 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           (group, column) pairs, stages, steps, work items, partial
  *                           slots, split groups}
  *   sgnn_tilegroup_fill     writes the plan (sgnn_tilegroup_plan_bytes of those counts)
- *                           from the same, untouched workspace
- * Per operand:
- *   sgnn_tilegroup_split_f32  planes <- fp16 hi / lo of (scale_row[i] * X[i, :]) (scale_row
- *                           nullable; utils.py:93 when it is dinv); `state` is 32 bytes of
- *                           device memory that carries the scale and the fall-back flag to
- *                           the SpMM call that follows on the same stream
- *   sgnn_spmm_tilegroup_f32   Y = diag(dinv_row) . (w_off * pattern + diag(corr)) . planes,
- *                           epilogue as sgnn_spmm_csr_f32.  corr (nullable, square matrices
- *                           only) = stored diagonal value - w_off per row: the loaders'
- *                           A + A^T carries 2.0 off the diagonal (data_loader.py:75) and
- *                           utils.py:83-86 puts 1.0 on it; its term is taken from X in fp32.
- *                           rowptr / colidx / vals / dinv_col / X / ldx /
- *                           csr_workspace describe the same product for the fall-back
- *                           (X and dinv_col as given to the split call, csr_workspace of
+ *                           from the same, untouched workspace.  The plan records its own
+ *                           counts; an SpMM launch whose counts differ raises the flag
+ *                           (bit 4) instead of reading the plan with the wrong layout.
+ * Per operand, `state` = sgnn_tilegroup_state_bytes(F) of device memory: the fall-back flag
+ * (second 32-bit word; first word: bit pattern of the largest magnitude seen), the count of
+ * tiny elements (fifth word), the work counter of the SpMM launch, and per feature the
+ * measured largest magnitude and the bound its scale derives from:
+ *   sgnn_tilegroup_amax_f32   clears `state` and measures max |scale_row[i] * X[i, f]| per feature
+ *   sgnn_tilegroup_planes_f32 planes <- fp16 hi / lo of (scale_row[i] * X[i, :]) at the scales the
+ *                           state's maxima give (scale_row nullable; utils.py:93 when it is
+ *                           dinv).  `plane_rows` = rows per 128-feature slice of `planes`
+ *                           (>= n: the n rows may be part of a larger operand, a rank's rows
+ *                           of a partitioned matrix, whose ranks have agreed on the maxima
+ *                           in between); `operand_rows` sizes the limit of tiny elements
+ *   sgnn_tilegroup_split_f32  both, for an operand that is split whole
+ *   sgnn_spmm_tilegroup_f32   Y = diag(dinv_row) . (w_off * (pattern . planes + addend) + diag(corr) . x'),
+ *                           epilogue as sgnn_spmm_csr_f32.  corr (nullable) = stored diagonal
+ *                           value - w_off per row: the loaders' A + A^T carries 2.0 off the
+ *                           diagonal (data_loader.py:75) and utils.py:83-86 puts 1.0 on it; x'
+ *                           is row x_row_offset + i of the operand, taken from X (times
+ *                           dinv_col) in fp32 where X is given, rebuilt from the planes
+ *                           otherwise.  addend (nullable, [n_rows, ld_addend]): raw sums of
+ *                           another column block of the same rows (a row partition
+ *                           multiplies its own-columns block while remote rows travel).
+ *                           rowptr / colidx / vals / dinv_col / X / ldx / csr_workspace
+ *                           describe the same product for the fall-back (X and dinv_col as
+ *                           given to the split call, csr_workspace of
  *                           sgnn_spmm_workspace_bytes); rowptr == NULL: no fall-back is
- *                           launched and Y is left untouched when state's flag is set.
+ *                           launched and the output is left untouched when the flag is set.
+ *                           planes_out != NULL: instead of Y the rows are written as the
+ *                           NEXT hop's operand -- fp16 planes of row i at node
+ *                           out_row_offset + i of a buffer of planes_out_rows rows per slice,
+ *                           `state_out` cleared and filled for it (its flag also inherits a
+ *                           refusal of this hop).  The next operand's scale per feature is
+ *                           derived from this operand's measured maximum (adapt = 1) or from
+ *                           this operand's own bound again (adapt = 0: ranks of a partition
+ *                           need no agreement): valid because dinv_row[i]^2 times row i's
+ *                           weights sum to at most one for the normalised adjacency
+ *                           (utils.py:88-95), so no element of D^-1 (A+I) x' exceeds the
+ *                           largest of x'; an operand that breaks the bound is caught by the
+ *                           element check and refused.
  *                           The launch is one workgroup per CU; the workgroups take (work
  *                           item, feature slice) pairs off a counter kept in `state`, which
  *                           the call zeroes: two SpMM calls that share a `state` must not
  *                           overlap (calls in one stream never do).
+ *   sgnn_tilegroup_chain_f32  Y = A_hat^K . X (utils.py:91-96, model/SGC.py:11): one split of X,
+ *                           K hops of which only the last writes fp32 -- the others write the
+ *                           next hop's planes from their epilogue, so no intermediate is
+ *                           stored as fp32, measured or split again -- then the plain CSR
+ *                           chain on the fp32 X behind the last operand's flag (its
+ *                           intermediates reuse the planes' memory).  planes_a / planes_b:
+ *                           sgnn_tilegroup_planes_bytes(n, F) each (planes_b only for K > 1);
+ *                           states: K blocks of sgnn_tilegroup_state_bytes(F).
  */
 /* Diagnostics: cycle counters of tile-group runs made with tuning key "tg_mode" bit 16 set (kernel,
  * stage waits, next-stage issue, step loops, wavefronts, steps, stages; summed over wavefronts);
  * reading clears them.  No counterpart in the reference. */
 int sgnn_tilegroup_debug_counters(unsigned long long* out8);
-/* Diagnostics: eight words per unit of work (item, feature slice) — wall clock (100 MHz) at the
+/* Diagnostics: eight words per unit of work (item, feature slice) -- wall clock (100 MHz) at the
  * start and the end of its stage loop, CU id, stages walked, wall clock when wavefront 0 had
- * written its rows, at entry, when the whole workgroup had fetched its next unit, one spare — for
+ * written its rows, at entry, when the whole workgroup had fetched its next unit, one spare -- for
  * the first `count` (at most 16384) units of the last tile-group SpMM launch made with tuning
  * key tg_mode bit 16 set; out is host memory of count * 64 bytes.  No reference counterpart. */
 int sgnn_tilegroup_debug_spans(unsigned long long* out, int64_t count);
@@ -246,6 +285,11 @@ int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t sta
                         int64_t long_groups, void* plan, size_t plan_bytes, void* workspace, size_t workspace_bytes,
                         void* stream);
 size_t sgnn_tilegroup_planes_bytes(int64_t n_cols, int64_t F);
+size_t sgnn_tilegroup_state_bytes(int64_t F);
+int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* state,
+                            void* stream);
+int sgnn_tilegroup_planes_f32(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* planes,
+                              int64_t plane_rows, int64_t operand_rows, void* state, void* stream);
 int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, const float* X, int64_t ldx,
                              void* planes, size_t planes_bytes, void* state, void* stream);
 size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F);
@@ -255,7 +299,16 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
                             size_t planes_bytes, void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
                             size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                             const float* vals, const float* dinv_col, const float* X, int64_t ldx,
-                            void* csr_workspace, size_t csr_workspace_bytes, void* stream);
+                            void* csr_workspace, size_t csr_workspace_bytes, int64_t x_row_offset, const float* addend,
+                            int64_t ld_addend, void* planes_out, int64_t planes_out_rows, int64_t out_row_offset,
+                            void* state_out, int adapt, void* stream);
+int sgnn_tilegroup_chain_f32(int K, int64_t n, int64_t F, const void* plan, size_t plan_bytes, int64_t stages,
+                             int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups, const float* dinv,
+                             float w_off, const float* corr, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                             void* planes_a, void* planes_b, size_t planes_bytes, void* states, size_t states_bytes,
+                             void* workspace, size_t workspace_bytes, int64_t nnz, const int32_t* rowptr,
+                             const int32_t* colidx, const float* vals, void* csr_workspace, size_t csr_workspace_bytes,
+                             void* stream);
 
 /*
  * Row-group form of a CSR's sparsity pattern, and the SpMM kernel that uses it.

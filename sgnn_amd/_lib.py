@@ -67,13 +67,23 @@ SIGNATURES = {
     "sgnn_tilegroup_fill": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t,
                                     c_void_p, c_size_t, c_void_p]),
     "sgnn_tilegroup_planes_bytes": (c_size_t, [c_int64, c_int64]),
+    "sgnn_tilegroup_state_bytes": (c_size_t, [c_int64]),
+    "sgnn_tilegroup_amax_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "sgnn_tilegroup_planes_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                          c_void_p, c_void_p]),
     "sgnn_tilegroup_split_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
                                          c_void_p]),
     "sgnn_spmm_tilegroup_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgnn_spmm_tilegroup_f32": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_size_t, c_int64, c_int64, c_int64,
                                         c_int64, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                         c_int64, c_int, c_void_p, c_size_t, c_int64, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                                        c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int,
+                                        c_void_p]),
+    "sgnn_tilegroup_chain_f32": (c_int, [c_int, c_int64, c_int64, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_int64,
+                                         c_int64, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
+                                         c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "sgnn_gae_targets_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -36,6 +36,8 @@
 //
 // Reference path served: the adj.mm of utils.py:94 with its two row scalings
 // (utils.py:93, 95) for adjacencies whose off-diagonal entries all carry one weight.
+#include <atomic>
+#include <cstddef>
 #include <cstring>
 #include <type_traits>
 
@@ -67,24 +69,37 @@ constexpr int kBitsBytes = kMaxStageSteps * 64;
 constexpr int kHdrBytes = 512;                   // first steps of this stage's and the next stages' sub-tiles
 constexpr int kColsBytes = 1024;                 // column ids of the next two stages
 constexpr int kStageBytes = kStageRowsBytes + kSlotsBytes + kBitsBytes + kHdrBytes + kColsBytes;   // 79360 = 155 * 512
-constexpr int kTableBytes = 512;                 // pattern table at LDS offset 0 (16 entries of 8 bytes, the rest unused); the stage buffers follow
+constexpr int kTableBytes = 1024;                // LDS offset 0: pattern table (16 entries of 8 bytes), the work ticket at 496, at 512 the 128 per-feature maxima of a unit's written operand; the stage buffers follow
+constexpr int kTicketOff = 496, kAmaxOff = 512;
+constexpr int kStageOutBytes = 16384;            // write-out staging per wavefront: 32 rows x 512 bytes
 constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;
 constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slack behind the step arrays (a stage's DMA over-reads)
 static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wavefront loads 16 rows of a stage");
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
+static_assert(kTableBytes + kWaves * kStageOutBytes <= kLdsBytes, "the write-out staging must fit the ring");
 
 int g_seg_stages = 0;     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
 int g_order_cols = 0;     // > 0: work items ordered by column blocks of this width; 0: longest first (sgnn_tune_set("tg_order", v))
 int g_tg_mode = 0;         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only; results are then wrong
 
-struct TgState {          // device words shared by the split pass and the SpMM
-  uint32_t amax_bits;     // bit pattern of max |scale_row * x|
-  uint32_t flag;          // != 0: X cannot go through the fp16 planes
-  float scale, inv_scale;
-  uint32_t tiny;          // nonzero elements more than 2^33 below the largest magnitude
+struct TgState {          // device words that carry an operand's scales and its fall-back flag to the SpMM that reads it
+  uint32_t amax_all;      // bit pattern of the largest |element| over all features (diagnostics)
+  uint32_t flag;          // != 0: the operand cannot go through the fp16 planes (1: an element, 2: too many tiny ones, 4: plan mismatch, 8: inherited from the hop before)
+  uint32_t rsv[2];
+  uint32_t tiny;          // nonzero elements that keep fewer than 17 of their bits in the planes
   uint32_t queue;         // next work index of the running SpMM launch (zeroed by the SpMM call)
-  uint32_t pad[2];
+  uint32_t tiny_limit;    // more tiny elements than this: fall back
+  uint32_t pad;
+  // [Fpad] per feature, the bit pattern of its largest |element| as measured while the operand
+  // was written, followed by [Fpad] the bound its scale was derived from.  An operand split
+  // from fp32 is measured first, so the two agree; one written by the epilogue of the hop
+  // before uses what was known when that hop started (bound_of) and is measured on the way out.
+  uint32_t amax[1];
 };
+constexpr size_t kStateHead = 32;
+static_assert(offsetof(TgState, amax) == kStateHead, "state header is eight words");
+__device__ __forceinline__ uint32_t* bound_of(TgState* s, int Fpad) { return s->amax + Fpad; }
+__device__ __forceinline__ const uint32_t* bound_of(const TgState* s, int Fpad) { return s->amax + Fpad; }
 
 // ---- plan ------------------------------------------------------------------------
 struct TgPlan {
@@ -325,7 +340,7 @@ __global__ void k_tg_totals(int64_t G, const uint32_t* __restrict__ gstage0, con
                             const uint32_t* __restrict__ nseg, const uint32_t* __restrict__ first,
                             const uint32_t* __restrict__ lseg, const uint32_t* __restrict__ slot0,
                             const uint32_t* __restrict__ lflag, const uint32_t* __restrict__ lidx, int seg,
-                            int64_t* __restrict__ counts) {
+                            int64_t n_rows, int64_t* __restrict__ counts) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const int64_t stages = gstage0[G];
   counts[1] = stages;
@@ -334,6 +349,7 @@ __global__ void k_tg_totals(int64_t G, const uint32_t* __restrict__ gstage0, con
   counts[4] = G > 0 ? int64_t(slot0[G - 1]) + lseg[G - 1] : 0;
   counts[5] = G > 0 ? int64_t(lidx[G - 1]) + lflag[G - 1] : 0;
   counts[6] = tg_seg_for(uint32_t(stages), seg);
+  counts[7] = n_rows;
 }
 
 // ---- plan construction, phase 1: contents -----------------------------------------
@@ -455,62 +471,75 @@ __global__ void k_tg_item_place(int64_t items, const uint64_t* __restrict__ keys
 }
 
 // ---- fp16 planes --------------------------------------------------------------------
+// One power-of-two scale per FEATURE: columns never mix in A . X (a feature's accumulators only
+// ever see that feature), so each feature column is brought into the planes' range on its own
+// and the accumulator is scaled back per feature in the epilogue.  Feature matrices whose
+// columns differ by many orders of magnitude stay accurate column by column.
+
+// Per-feature max |scale_row[i] * X[i, f]| (bit patterns; NaN and inf compare above every finite
+// value) into state->amax.  A workgroup's threads lie along the features, V = 1 or 2 consecutive
+// ones per thread; rows are walked four at a time so that four loads are in flight per lane; a
+// narrow row leaves room for several row quadruples side by side (`subs`), folded through LDS.
 __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, const float* __restrict__ scale_row,
                                                  const float* __restrict__ X, int64_t ldx, TgState* __restrict__ state) {
-  uint32_t m = 0;
-  // a workgroup walks whole rows, four at a time so that four loads are in flight per lane
-  // (lanes along the features, 8-byte loads where the row allows)
+  __shared__ uint32_t smax[2048];
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
-  // A narrow row does not fill the workgroup: `lanes_row` threads (whole wavefronts) take a row
-  // and the workgroup walks blockDim / lanes_row quadruples of rows side by side.
-  const int per_row = pairs ? int((F + 1) / 2) : int(F);
+  const int V = pairs ? 2 : 1;
+  const int per_row = int((F + V - 1) / V);
   const int lanes_row = per_row >= int(blockDim.x) ? int(blockDim.x) : (per_row + kWave - 1) / kWave * kWave;
   const int subs = int(blockDim.x) / lanes_row, sub = int(threadIdx.x) / lanes_row, tin = int(threadIdx.x) % lanes_row;
-  for (int64_t r0 = 4 * (int64_t(blockIdx.x) * subs + sub); sub < subs && r0 < n; r0 += 4 * int64_t(gridDim.x) * subs) {
-    float sr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sr[i] = (r0 + i < n) ? (scale_row ? scale_row[r0 + i] : 1.0f) : 0.0f;
-    if (pairs) {
-      for (int64_t f = 2 * int64_t(tin); f < F; f += 2 * int64_t(lanes_row)) {
+  uint32_t all = 0;
+  for (int64_t fbase = 0; fbase < F; fbase += int64_t(V) * lanes_row) {
+    const int64_t f = fbase + int64_t(V) * tin;
+    uint32_t m0 = 0, m1 = 0;
+    if (sub < subs && f < F) {
+      for (int64_t r0 = 4 * (int64_t(blockIdx.x) * subs + sub); r0 < n; r0 += 4 * int64_t(gridDim.x) * subs) {
+        float sr[4];
         float2 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          sr[i] = (r0 + i < n) ? (scale_row ? scale_row[r0 + i] : 1.0f) : 0.0f;
           v[i] = float2{0.0f, 0.0f};
           if (r0 + i < n) {
             const float* row = X + (r0 + i) * ldx;
-            if (f + 1 < F) v[i] = *reinterpret_cast<const float2*>(row + f);
+            if (pairs && f + 1 < F) v[i] = *reinterpret_cast<const float2*>(row + f);
             else v[i].x = row[f];
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const uint32_t b0 = __builtin_bit_cast(uint32_t, v[i].x * sr[i]) & 0x7FFFFFFFu;   // |v|; NaN and inf compare above every finite value
+          const uint32_t b0 = __builtin_bit_cast(uint32_t, v[i].x * sr[i]) & 0x7FFFFFFFu;
           const uint32_t b1 = __builtin_bit_cast(uint32_t, v[i].y * sr[i]) & 0x7FFFFFFFu;
-          m = b0 > m ? b0 : m;
-          m = b1 > m ? b1 : m;
+          m0 = b0 > m0 ? b0 : m0;
+          m1 = b1 > m1 ? b1 : m1;
         }
       }
-    } else {
-      for (int i = 0; i < 4 && r0 + i < n; ++i)
-        for (int64_t f = tin; f < F; f += lanes_row) {
-          const uint32_t b0 = __builtin_bit_cast(uint32_t, X[(r0 + i) * ldx + f] * sr[i]) & 0x7FFFFFFFu;
-          m = b0 > m ? b0 : m;
-        }
+    }
+    if (subs > 1) {          // workgroup-uniform
+      for (int i = threadIdx.x; i < 2 * lanes_row; i += blockDim.x) smax[i] = 0;
+      __syncthreads();
+      if (sub < subs && f < F) {
+        if (m0) atomicMax(&smax[2 * tin], m0);
+        if (m1) atomicMax(&smax[2 * tin + 1], m1);
+      }
+      __syncthreads();
+      m0 = smax[2 * tin];
+      m1 = smax[2 * tin + 1];
+      __syncthreads();
+    }
+    if (sub == 0 && f < F) {
+      if (m0) atomicMax(&state->amax[f], m0);
+      if (V == 2 && f + 1 < F && m1) atomicMax(&state->amax[f + 1], m1);
+      all = m0 > all ? m0 : all;
+      all = m1 > all ? m1 : all;
     }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const uint32_t o = uint32_t(__shfl_xor(int(m), off));
-    m = o > m ? o : m;
+    const uint32_t o = uint32_t(__shfl_xor(int(all), off));
+    all = o > all ? o : all;
   }
-  // one atomic per workgroup: they all hit one word, which takes them one at a time
-  __shared__ uint32_t wave_max[16];
-  if ((threadIdx.x & (kWave - 1)) == 0) wave_max[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (unsigned i = 1; i < blockDim.x / kWave; ++i) m = wave_max[i] > m ? wave_max[i] : m;
-    if (m != 0) atomicMax(&state->amax_bits, m);
-  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && all) atomicMax(&state->amax_all, all);
 }
 
 // the power of two that brings amax into [2^14, 2^15)
@@ -523,19 +552,30 @@ __device__ __forceinline__ float tg_scale(uint32_t amax_bits) {
   return __builtin_bit_cast(float, uint32_t(s + 127) << 23);
 }
 
-// planes[slice][node] = 128 halfs hi | 128 halfs lo of (scale_row[node] * X[node, slice]) * scale.
+// One element into its two planes: xs = hi + lo / 2048 to 2^-22 of xs (fp16 carries 11 bits, the
+// remainder times 2048 another 11) down to the spacing of the lo plane's subnormals, 2^-35.
+// `bad`: the pair does not reproduce xs to 2^-21 (non-finite values included: `!(<=)` catches NaN);
+// `tiny`: a nonzero element so far below its feature's bound that fewer than 17 bits survive.
+__device__ __forceinline__ void tg_split_one(float xv, float scale, _Float16& h, _Float16& l, bool& bad, uint32_t& tiny) {
+  const float xs = xv * scale;
+  h = _Float16(xs);
+  const float r = xs - float(h);
+  l = _Float16(r * 2048.0f);
+  const float back = float(h) + float(l) * (1.0f / 2048.0f);
+  const float ax = __builtin_fabsf(xs);
+  bad |= !(__builtin_fabsf(xs - back) <= __builtin_fmaxf(ax * 4.8e-7f, 3.0e-11f));
+  tiny += (xv != 0.0f && ax < 1.9e-6f) ? 1u : 0u;   // below 2^-19 (or flushed to 0)
+}
+
+// planes[slice][node] = 128 halfs hi | 128 halfs lo of (scale_row[node] * X[node, slice]) * scale[feature].
 // One workgroup walks whole nodes; a thread takes a pair of neighbouring features (one 8-byte
 // read where the row allows it, one 4-byte store into each plane: both coalesced).
+// slice_stride = bytes between a node's consecutive slices (the planes may belong to a larger
+// operand of which these n nodes are a part: a rank's rows of a partitioned matrix).
 __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t n_slices,
                                                   const float* __restrict__ scale_row, const float* __restrict__ X,
-                                                  int64_t ldx, char* __restrict__ planes, TgState* __restrict__ state) {
-  const uint32_t amax = state->amax_bits;
-  const float scale = tg_scale(amax);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    state->scale = scale;
-    state->inv_scale = 1.0f / scale;
-    if (amax >= 0x7F800000u) atomicOr(&state->flag, 1u);
-  }
+                                                  int64_t ldx, char* __restrict__ planes, int64_t slice_stride,
+                                                  TgState* __restrict__ state) {
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
   const int64_t Fpad = n_slices * kSlice;
   bool bad = false;
@@ -546,10 +586,19 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
   const int per_node = int(Fpad / 2);
   const int lanes_node = per_node >= int(blockDim.x) ? int(blockDim.x) : per_node;   // a multiple of 64
   const int subs = int(blockDim.x) / lanes_node, sub = int(threadIdx.x) / lanes_node, tin = int(threadIdx.x) % lanes_node;
+  // a thread's features are the same for every node: their scales, for the first few chunks, are kept in registers
+  constexpr int kKeep = 4;
+  float sc[kKeep][2];
+#pragma unroll
+  for (int c = 0; c < kKeep; ++c) {
+    const int64_t f = 2 * int64_t(tin) + 2 * int64_t(lanes_node) * c;
+    sc[c][0] = f < F ? tg_scale(state->amax[f]) : 1.0f;
+    sc[c][1] = f + 1 < F ? tg_scale(state->amax[f + 1]) : 1.0f;
+  }
   for (int64_t node = int64_t(blockIdx.x) * subs + sub; sub < subs && node < n; node += int64_t(gridDim.x) * subs) {
     const float sr = scale_row ? scale_row[node] : 1.0f;
     const float* row = X + node * ldx;
-    for (int64_t f = 2 * int64_t(tin); f < Fpad; f += 2 * int64_t(lanes_node)) {
+    auto body = [&](int64_t f, float s0, float s1) {
       float x[2] = {0.0f, 0.0f};
       if (f + 1 < F && pairs) {
         const float2 v = *reinterpret_cast<const float2*>(row + f);
@@ -560,30 +609,24 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
         if (f + 1 < F) x[1] = row[f + 1];
       }
       _Float16 hi[2], lo[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float xv = x[j] * sr;                  // the reference's scaling (utils.py:93), fp32
-        const float xs = xv * scale;
-        const _Float16 h = _Float16(xs);
-        const float r = xs - float(h);
-        const _Float16 l = _Float16(r * 2048.0f);
-        const float back = float(h) + float(l) * (1.0f / 2048.0f);
-        // hi + lo / 2048 carries 22 bits of the input down to the spacing of the lo plane's
-        // subnormals (2^-35 here, 2^-50 of the largest magnitude); `!(<=)` also catches NaN
-        const float ax = __builtin_fabsf(xs);
-        bad |= !(__builtin_fabsf(xs - back) <= __builtin_fmaxf(ax * 4.8e-7f, 3.0e-11f));
-        tiny += (xv != 0.0f && ax < 1.9e-6f) ? 1u : 0u;   // below 2^-19 (or flushed to 0): fewer than 17 of its bits survive
-        hi[j] = h;
-        lo[j] = l;
-      }
+      tg_split_one(x[0] * sr, s0, hi[0], lo[0], bad, tiny);   // x * sr: the reference's scaling (utils.py:93), fp32
+      tg_split_one(x[1] * sr, s1, hi[1], lo[1], bad, tiny);
       const int64_t slice = f / kSlice;
       const int within = int(f % kSlice);
-      char* dst = planes + ((slice * n + node) * kRowBytes) + within * 2;
+      char* dst = planes + slice * slice_stride + node * kRowBytes + within * 2;
       *reinterpret_cast<uint32_t*>(dst) =
           uint32_t(__builtin_bit_cast(uint16_t, hi[0])) | (uint32_t(__builtin_bit_cast(uint16_t, hi[1])) << 16);
       *reinterpret_cast<uint32_t*>(dst + kRowBytes / 2) =
           uint32_t(__builtin_bit_cast(uint16_t, lo[0])) | (uint32_t(__builtin_bit_cast(uint16_t, lo[1])) << 16);
+    };
+    int64_t f = 2 * int64_t(tin);
+#pragma unroll
+    for (int c = 0; c < kKeep; ++c) {
+      if (f < Fpad) body(f, sc[c][0], sc[c][1]);
+      f += 2 * int64_t(lanes_node);
     }
+    for (; f < Fpad; f += 2 * int64_t(lanes_node))
+      body(f, f < F ? tg_scale(state->amax[f]) : 1.0f, f + 1 < F ? tg_scale(state->amax[f + 1]) : 1.0f);
   }
   // one atomic per wavefront
 #pragma unroll
@@ -595,11 +638,19 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
   }
 }
 
-// A continuous distribution leaves a handful of such elements among 10^8 (they change a sum
-// by less than 2^-50 of the largest magnitude each); data with a genuinely wide dynamic
-// range has them by the thousand and goes to the fall-back kernel.
-__global__ void k_tg_finish(TgState* __restrict__ state, uint32_t tiny_limit) {
-  if (state->tiny > tiny_limit) atomicOr(&state->flag, 2u);
+// A continuous distribution leaves a handful of tiny elements among 10^8 (they change a sum
+// by less than 2^-50 of their feature's largest magnitude each); data with a genuinely wide
+// dynamic range inside a column has them by the thousand and goes to the fall-back kernel.
+__host__ __device__ inline uint32_t tg_tiny_limit(int64_t elements) {
+  const int64_t lim = elements >> 20;
+  return uint32_t(lim > 16 ? (lim < 0x7fffffff ? lim : 0x7fffffff) : 16);
+}
+
+// an operand split from fp32: its scales derive from its own measured maxima
+__global__ void k_tg_state_init(TgState* __restrict__ state, uint32_t tiny_limit, int Fpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) state->tiny_limit = tiny_limit;
+  if (i < Fpad) bound_of(state, Fpad)[i] = state->amax[i];
 }
 
 // cycle counts of a diagnostic run (mode bit 16): kernel, waits for a stage, issue of the next
@@ -616,25 +667,37 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct TgArgs {
+  const int64_t* plan_counts;   // the plan's own counts, checked against the launch's
   const int32_t *grows, *stage_col, *step0;
   const uint16_t* step_slots;
   const uint16_t* step_bits;
   const int32_t *item_group, *item_s0, *item_s1, *item_out;
   const int32_t *long_group, *long_slot, *long_nseg;
   const char* planes;
-  const TgState* state;
+  TgState* state;    // of the operand in `planes`
   uint32_t* queue;   // work counter of this launch (in the state words)
   const float* dinv_row;
   // diagonal of its own (A + A^T has weight 2 off the diagonal, A + I puts 1 on it): the
   // weighted row sum is w_off * (pattern sum) + corr[i] * x'_i with x' the operand as the
-  // planes hold it, i.e. X (times dinv_col per row when that is given); NULL = none
+  // planes hold it; read from X in fp32 (times dinv_col per row when that is given) where the
+  // caller has it, else rebuilt from the planes.  Row i's own operand row is x_row_offset + i.
   const float *corr, *X, *dinv_col;
   float *Y, *partial;
-  int64_t ldy, ldx, slice_bytes;   // slice_bytes = n_cols * 512
-  int32_t items, n_long, F, Fpad, epilogue;
+  // raw sums of another column block of the same rows (a partitioned matrix multiplies its
+  // own-columns block while the remote rows travel), added to the pattern sum; NULL = none
+  const float* addend;
+  // != NULL: the rows are written as the NEXT hop's operand planes (fp16 hi / lo, scale per
+  // feature from this operand's bound) instead of fp32 Y: row i at node out_row_offset + i
+  char* planes_out;
+  TgState* state_out;
+  int64_t ldy, ldx, ld_addend, slice_bytes, slice_bytes_out;   // slice_bytes = n_cols * 512
+  int64_t x_row_offset, out_row_offset, n_rows;
+  int32_t items, n_long, F, Fpad, epilogue, stages, steps;
   float w_off;
   int32_t mode;
   int32_t slices;
+  uint32_t tiny_limit_out;
+  int32_t adapt;   // 1: the next operand's bound is this operand's measured maximum, 0: this operand's bound again
 };
 
 // LDS-DMA: 64 lanes x 16 (4) bytes from per-lane global addresses to LDS [lds, lds + 1024 (256)).
@@ -664,11 +727,19 @@ __device__ __forceinline__ __attribute__((address_space(3))) T* lds(uint32_t off
 // NT = the slice's N-tiles of 32 features that hold features below F (the last slice of a
 // width that is not a multiple of 128, every slice of a narrow one): the tiles beyond are
 // fetched with the row but neither read from LDS nor multiplied.
+// the launch's arguments as they lie in the kernel-argument segment (scalar loads at the point of use)
+typedef const __attribute__((address_space(4))) TgArgs TgKernArgs;
+
 template <int NT, bool DIAG>
-__device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const int slice, const int work) {
+__device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int slice, const int work) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned long long wall_entry = (a.mode & 16) ? wall_clock64() : 0;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  // (the thread id passes through an empty asm statement: everything derived from it is then
+  // computed per unit of work instead of being hoisted out of the kernel's work loop, where the
+  // lane constants of all eight instances of this function would stay live side by side)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = a.item_group[item], s0 = a.item_s0[item], s1 = a.item_s1[item], out = a.item_out[item];
   constexpr uint32_t lds0 = 0;   // LDS address of smem: the dynamic segment follows the static one, and there is none
@@ -764,14 +835,12 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
   // The wavefront's 64 rows and their scales for the write-out, one per lane (a coalesced load
   // and a gather): asked for here, two dependent trips to memory ahead of the stage loop
   // instead of behind it.
-  const float inv_scale_v = a.state->inv_scale;
   const int my_row = a.grows[int64_t(g) * kRows + 2 * kSub * w + lane];
   float my_dr = 1.0f, my_cr = 0.0f;
   if (out < 0 && my_row >= 0) {
     if (a.dinv_row != nullptr) my_dr = a.dinv_row[my_row];
-    if (DIAG) my_cr = a.corr[my_row] * (a.dinv_col != nullptr ? a.dinv_col[my_row] : 1.0f);
+    if (DIAG) my_cr = a.corr[my_row] * ((a.X != nullptr && a.dinv_col != nullptr) ? a.dinv_col[a.x_row_offset + my_row] : 1.0f);
   }
-
   const bool dbg = (a.mode & 16) != 0;
   unsigned long long t_wait = 0, t_issue = 0, t_steps = 0, n_steps = 0;
   const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -977,17 +1046,18 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     atomicAdd(&g_tg_dbg[6], (unsigned long long)ns);
   }
 
+  // ---- write-out -------------------------------------------------------------------------
   // Accumulator register v of a lane: row (v & 3) + 8 (v >> 2) + 4 h of the sub-tile, feature
-  // lane & 31 of the N-tile.  The wavefront's 64 rows and their scales, looked up once per lane
-  // before the stage loop, are handed out by v_readlane: looked up row by row, two dependent
-  // loads stood in front of every one of the 32 row pairs and writing the rows out took 40 us
-  // of a 380 us unit of work.
-  // The three values came from memory; the unrolled write-out below reads them through
-  // v_readlane in many basic blocks, and the compiler, unable to prove across the branches that
-  // the loads have landed, put a wait for ALL outstanding memory operations in front of every
-  // row: every row waited for the stores of the row before to be acknowledged (22 us per unit
-  // of work).  Copied once through a register move they are plain register values.
-  const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, inv_scale_v)));   // (the same holds for the scale)
+  // lane & 31 of the N-tile.  Stored from there a wave instruction would carry two 128-byte row
+  // pieces (or, for fp16 planes, two of 64 bytes); the rows go through LDS instead -- the ring
+  // is free once every wavefront has left the stage loop -- and leave as whole 512-byte rows,
+  // 16 bytes per lane.  Each wavefront stages its own 32 rows of a sub-tile, so nothing but the
+  // one barrier in front is needed (a wavefront's LDS accesses execute in order).
+  // The wavefront's 64 rows and their scales, looked up once per lane before the stage loop,
+  // are handed out by v_readlane.  They came from memory; copied once through a register move
+  // they are plain register values (otherwise the compiler, unable to prove across the branches
+  // of the unrolled write-out that the loads have landed, waits for ALL outstanding memory
+  // operations, the stores of the row before included, in front of every row).
   int row_v, dr_v, cr_v;
   asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
                : "=&v"(row_v), "=&v"(dr_v), "=&v"(cr_v)
@@ -997,48 +1067,163 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
     return h ? hi : lo;
   };
   if (a.mode & 32) return;   // diagnostics: nothing written
+  const bool to_planes = out < 0 && a.planes_out != nullptr;   // uniform
+  // The bounds of this lane's features (one per N-tile): the power of two the accumulators are
+  // scaled back by, and the scale of the operand written for the next hop.  A row of
+  // D^-1 (A + I) sums to one, so no element of that operand exceeds the largest of the operand
+  // read here: that measured maximum (or, where ranks would have to agree on it first, the
+  // older bound) is the next operand's bound.
+  float inv_sc[NT], sc_out[NT];
+  uint32_t mx[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int f = slice * kSlice + nt * 32 + (lane & 31);
+    const uint32_t bnd = bound_of(a.state, a.Fpad)[f];
+    const uint32_t nxt = (to_planes && a.adapt) ? a.state->amax[f] : bnd;
+    const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
+    inv_sc[nt] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);   // 1 / scale, exact: a power of two
+    sc_out[nt] = tg_scale(nxt);
+    mx[nt] = 0;
+  }
+  bool bad = false;
+  uint32_t tiny = 0;
+  __builtin_amdgcn_s_barrier();   // the ring is no longer read
+  const uint32_t stg = uint32_t(kTableBytes) + uint32_t(w) * uint32_t(kStageOutBytes);
+  const bool y4 = (a.ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 16 == 0);
+  const bool y2 = (a.ldy % 2 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 8 == 0);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
-    const int t = 2 * w + tt;
-    // Diagonal correction: the sub-tile's own elements of X, all 16 rows' worth asked for in one
-    // go and without a branch around any load (a row that does not exist reads row 0, a feature
-    // past F reads the last one; neither value is used), so that one wait covers them; loaded
-    // where they are used, every element stood behind a wait for everything outstanding.
     const bool diag = DIAG && out < 0;   // uniform (DIAG: the launch has a diagonal correction)
-    [[maybe_unused]] float xq[DIAG ? 16 : 1][NT];
-    if constexpr (DIAG) if (diag) {
+    const bool add = out < 0 && a.addend != nullptr;   // uniform
+    // four accumulator registers (eight rows of the sub-tile) at a time: what they need from
+    // memory -- the other column block's raw sums, the rows' own operand elements for the diagonal
+    // correction -- is asked for in one go and without a branch around any load (a row that does
+    // not exist reads row 0, a feature past F reads the last one; neither value is used), so that
+    // one wait covers it.
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int row = max(pick(row_v, kSub * tt + (v & 3) + 8 * (v >> 2)), 0);
+    for (int v0 = 0; v0 < 16; v0 += 4) {
+      [[maybe_unused]] float xq[4][NT], aq[4][NT];
+      if constexpr (DIAG) if (diag) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          xq[v][nt] = a.X[int64_t(row) * a.ldx + min(slice * kSlice + nt * 32 + (lane & 31), a.F - 1)];
+        for (int i = 0; i < 4; ++i) {
+          const int v = v0 + i;
+          const int64_t node = a.x_row_offset + max(pick(row_v, kSub * tt + (v & 3) + 8 * (v >> 2)), 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (a.X != nullptr) {
+              xq[i][nt] = a.X[node * a.ldx + min(slice * kSlice + nt * 32 + (lane & 31), a.F - 1)];
+            } else {   // the operand exists only as planes: hi + lo / 2048, scaled back
+              const char* pr = xs + node * kRowBytes + (nt * 32 + (lane & 31)) * 2;
+              const float hv = float(*reinterpret_cast<const _Float16*>(pr));
+              const float lv = float(*reinterpret_cast<const _Float16*>(pr + kRowBytes / 2));
+              xq[i][nt] = (hv + lv * (1.0f / 2048.0f)) * inv_sc[nt];
+            }
+          }
+        }
+      }
+      if (add) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int v = v0 + i;
+          const int row = max(pick(row_v, kSub * tt + (v & 3) + 8 * (v >> 2)), 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            aq[i][nt] = a.addend[int64_t(row) * a.ld_addend + min(slice * kSlice + nt * 32 + (lane & 31), a.F - 1)];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = v0 + i;
+        const int src = kSub * tt + (v & 3) + 8 * (v >> 2);
+        const uint32_t rl = uint32_t((v & 3) + 8 * (v >> 2) + 4 * h);   // row inside the sub-tile
+        const int row = pick(row_v, src);
+        const float dr = __builtin_bit_cast(float, pick(dr_v, src));
+        const float cr = __builtin_bit_cast(float, pick(cr_v, src));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const uint32_t fl = uint32_t(nt * 32 + (lane & 31));   // feature inside the slice
+          float y = acc[tt][nt][v] * inv_sc[nt];   // exact: a power of two
+          if (out < 0) {
+            if (add) y += aq[i][nt];
+            if constexpr (DIAG) y = fmaf(a.w_off, y, cr * xq[i][nt]);
+            else if (a.w_off != 1.0f) y *= a.w_off;
+            if (a.dinv_row != nullptr) {
+              y = y * dr;
+              if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+            }
+            if (row < 0) y = 0.0f;
+          }
+          if (to_planes) {
+            _Float16 hv, lv;
+            tg_split_one(y, sc_out[nt], hv, lv, bad, tiny);
+            const uint32_t yb = __builtin_bit_cast(uint32_t, y) & 0x7FFFFFFFu;
+            mx[nt] = yb > mx[nt] ? yb : mx[nt];
+            *lds<_Float16>(stg + rl * uint32_t(kRowBytes) + fl * 2u) = hv;
+            *lds<_Float16>(stg + rl * uint32_t(kRowBytes) + uint32_t(kRowBytes / 2) + fl * 2u) = lv;
+          } else {
+            *lds<float>(stg + rl * uint32_t(kRowBytes) + fl * 4u) = y;
+          }
+        }
       }
     }
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int src = kSub * tt + (v & 3) + 8 * (v >> 2);
-      const int rr = kSub * t + (v & 3) + 8 * (v >> 2) + 4 * h;
-      const int row = pick(row_v, src);
-      if (row < 0) continue;
-      const float dr = __builtin_bit_cast(float, pick(dr_v, src));
-      const float cr = __builtin_bit_cast(float, pick(cr_v, src));
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int f = slice * kSlice + nt * 32 + (lane & 31);
-        float y = acc[tt][nt][v] * inv_scale;   // exact: a power of two
-        if (out < 0) {
-          if (f >= a.F) continue;
-          if constexpr (DIAG) y = fmaf(a.w_off, y, cr * xq[v][nt]);
-          else if (a.w_off != 1.0f) y *= a.w_off;
-          if (a.dinv_row != nullptr) {
-            y = y * dr;
-            if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
-          }
-          a.Y[int64_t(row) * a.ldy + f] = y;
+    // the staged rows leave 16 bytes per lane: instruction j carries rows 2 j and 2 j + 1
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int lo_row = __builtin_amdgcn_readlane(row_v, kSub * tt + 2 * j);
+      const int hi_row = __builtin_amdgcn_readlane(row_v, kSub * tt + 2 * j + 1);
+      const int row = h ? hi_row : lo_row;
+      const f32x4 q4 = *lds<const f32x4>(stg + uint32_t(j) * 1024u + uint32_t(lane) * 16u);
+      const int c = lane & 31;   // which 16 bytes of the row
+      if (to_planes) {
+        if (row < 0) continue;
+        // chunks 0..15: hi plane, 8 features each; 16..31: lo plane.  N-tiles this unit did not compute hold zeros.
+        const bool live = ((c & 15) >> 2) < NT;
+        const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        *reinterpret_cast<f32x4*>(a.planes_out + int64_t(slice) * a.slice_bytes_out + (a.out_row_offset + row) * kRowBytes + c * 16) =
+            live ? q4 : z4;
+      } else if (out < 0) {
+        if (row < 0) continue;
+        const int f = slice * kSlice + 4 * c;
+        float* dst = a.Y + int64_t(row) * a.ldy + f;
+        if (f + 4 <= a.F && y4) {
+          *reinterpret_cast<f32x4*>(dst) = q4;
+        } else if (f + 4 <= a.F && y2) {
+          *reinterpret_cast<f32x2*>(dst) = f32x2{q4[0], q4[1]};
+          *reinterpret_cast<f32x2*>(dst + 2) = f32x2{q4[2], q4[3]};
         } else {
-          a.partial[(int64_t(out) * kRows + rr) * a.Fpad + f] = y;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (f + i < a.F) dst[i] = q4[i];
         }
+      } else {
+        const int rr = 2 * kSub * w + kSub * tt + 2 * j + h;
+        *reinterpret_cast<f32x4*>(a.partial + (int64_t(out) * kRows + rr) * a.Fpad + slice * kSlice + 4 * c) = q4;
+      }
+    }
+  }
+  if (to_planes) {
+    // what the next hop needs to know about the operand just written: whether the planes hold
+    // it, and each feature's largest magnitude (the bound of the hop after next)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
+    const bool any_bad = __any(bad);
+    if (lane == 0) {
+      if (tiny) atomicAdd(&a.state_out->tiny, tiny);
+      if (any_bad) atomicOr(&a.state_out->flag, 1u);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint32_t o = uint32_t(__shfl_xor(int(mx[nt]), 32));
+      const uint32_t m = o > mx[nt] ? o : mx[nt];
+      if (h == 0 && m) atomicMax(reinterpret_cast<uint32_t*>(smem + kAmaxOff) + (nt * 32 + lane), m);
+    }
+    __syncthreads();
+    if (tid < kSlice) {
+      const uint32_t m = *lds<uint32_t>(uint32_t(kAmaxOff) + uint32_t(tid) * 4u);
+      if (m) {
+        atomicMax(&a.state_out->amax[slice * kSlice + tid], m);
+        atomicMax(&a.state_out->amax_all, m);
+        *lds<uint32_t>(uint32_t(kAmaxOff) + uint32_t(tid) * 4u) = 0u;
       }
     }
   }
@@ -1049,16 +1234,42 @@ __device__ __forceinline__ void tg_run(const TgArgs& a, const int item, const in
 // stay together in time, which keeps a slice's hot rows in L2 (slice index fastest was tried:
 // 9 % slower), and a slice ends on its short items; launching the long items of all slices
 // ahead of all the short ones was tried and made no difference once the counter was in.
+// the operand cannot go through the planes (or the launch does not match the plan): nothing is
+// computed here and the fall-back behind the launch, guarded by state->flag, takes over
+__device__ __forceinline__ bool tg_refused(const TgArgs& a, bool first_thread) {
+  const TgState* st = a.state;
+  const bool many_tiny = st->tiny > st->tiny_limit;
+  const int64_t* pc = a.plan_counts;
+  const bool mismatch = pc[1] != a.stages || pc[2] != a.steps || pc[3] != a.items || pc[5] != a.n_long || pc[7] != a.n_rows;
+  const bool refused = st->flag != 0 || many_tiny || mismatch;
+  if (refused && first_thread) {
+    const uint32_t bits = (many_tiny ? 2u : 0u) | (mismatch ? 4u : 0u);
+    if (bits) atomicOr(&a.state->flag, bits);
+    if (a.state_out != nullptr) atomicOr(&a.state_out->flag, 8u);   // the hops behind this one have no operand
+  }
+  return refused;
+}
+
 __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  if (a.state->flag != 0) return;   // X did not fit the fp16 planes: the fall-back kernel computes Y
+  if (tg_refused(a, blockIdx.x == 0 && threadIdx.x == 0)) return;
+  if (a.state_out != nullptr) {
+    // the next operand's bounds (see tg_run) and its limit of tiny elements
+    for (int sl = blockIdx.x; sl < a.slices; sl += gridDim.x)
+      if (threadIdx.x < kSlice) {
+        const int f = sl * kSlice + threadIdx.x;
+        bound_of(a.state_out, a.Fpad)[f] = a.adapt ? a.state->amax[f] : bound_of(a.state, a.Fpad)[f];
+      }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.state_out->tiny_limit = a.tiny_limit_out;
+  }
+  if (threadIdx.x < kSlice) *lds<uint32_t>(uint32_t(kAmaxOff) + threadIdx.x * 4u) = 0u;
   const int total = a.items * a.slices;
   // One workgroup per CU for the whole launch, taking (item, slice) pairs off a counter: a
   // workgroup holds all of a CU's LDS, so a fresh one can only be placed when the last has gone,
   // and between two workgroups of a one-per-pair grid a CU sat idle for tens of microseconds
   // (Reddit shape: 5.27 ms per hop with the counter against 5.48 ms with one workgroup per
   // pair).  Every wavefront leaves through the same test of b.
-  int* next = reinterpret_cast<int*>(smem + kTableBytes - 16);   // behind the pattern table, before the ring
+  int* next = reinterpret_cast<int*>(smem + kTicketOff);   // behind the pattern table
   int prev = -1;
   for (;;) {
     int b = blockIdx.x;
@@ -1073,16 +1284,21 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     if (b >= total) break;
     const int slice = b / a.items, item = b - slice * a.items;
     const int tiles = (min(kSlice, a.F - slice * kSlice) + 31) / 32;   // workgroup-uniform
+    // A unit of work reads the launch's arguments where it needs them, through a pointer the
+    // compiler cannot see through: held in registers across the work loop (eight instances of
+    // tg_run, each with its own derived values) they cost more registers than the wavefront has.
+    TgKernArgs* ka = (TgKernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
     if (a.corr != nullptr) {   // the same for every unit of the launch
-      if (tiles >= 4) tg_run<4, true>(a, item, slice, b);
-      else if (tiles == 3) tg_run<3, true>(a, item, slice, b);
-      else if (tiles == 2) tg_run<2, true>(a, item, slice, b);
-      else tg_run<1, true>(a, item, slice, b);
+      if (tiles >= 4) tg_run<4, true>(*ka, item, slice, b);
+      else if (tiles == 3) tg_run<3, true>(*ka, item, slice, b);
+      else if (tiles == 2) tg_run<2, true>(*ka, item, slice, b);
+      else tg_run<1, true>(*ka, item, slice, b);
     } else {
-      if (tiles >= 4) tg_run<4, false>(a, item, slice, b);
-      else if (tiles == 3) tg_run<3, false>(a, item, slice, b);
-      else if (tiles == 2) tg_run<2, false>(a, item, slice, b);
-      else tg_run<1, false>(a, item, slice, b);
+      if (tiles >= 4) tg_run<4, false>(*ka, item, slice, b);
+      else if (tiles == 3) tg_run<3, false>(*ka, item, slice, b);
+      else if (tiles == 2) tg_run<2, false>(*ka, item, slice, b);
+      else tg_run<1, false>(*ka, item, slice, b);
     }
     if (a.mode & 128) break;   // diagnostics: one workgroup per (item, slice) pair
   }
@@ -1090,7 +1306,13 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
 
 // rows of a group cut into several items: add the items' partial rows in order, then the row epilogue
 __global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
-  if (a.state->flag != 0) return;
+  if (tg_refused(a, false)) return;
+  __shared__ uint32_t smax[1024];   // per-feature maxima of the rows written as planes (widths beyond 1024 go straight to memory)
+  const bool to_planes = a.planes_out != nullptr;
+  if (to_planes) {
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) smax[i] = 0;
+    __syncthreads();
+  }
   const int li = blockIdx.x;
   const int g = a.long_group[li], slot = a.long_slot[li], nseg = a.long_nseg[li];
   const int64_t stride = int64_t(kRows) * a.Fpad;
@@ -1098,16 +1320,22 @@ __global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
   // run over the (row, four features) pairs of those rows, so that none idles when F / 4 is not
   // a multiple of the workgroup size (the partial rows are padded to whole slices and 16-byte
   // aligned).  The partial sums of a pair are loaded four at a time and added in item order.
-  const int quads = (a.F + 3) / 4;
+  // As planes the rows are written whole, padding features included (they are zero).
+  const int Fw = to_planes ? a.Fpad : a.F;
+  const int quads = (Fw + 3) / 4;
   const int my_rows = (kRows - int(blockIdx.y) + int(gridDim.y) - 1) / int(gridDim.y);
   const bool scale = a.dinv_row != nullptr;
+  bool bad = false;
+  uint32_t tiny = 0;
   for (int p = threadIdx.x; p < my_rows * quads; p += blockDim.x) {
     const int rr = int(blockIdx.y) + (p / quads) * int(gridDim.y);
     const int f4 = (p % quads) * 4;
     const int row = a.grows[int64_t(g) * kRows + rr];
     if (row < 0) continue;
     const float dr = scale ? a.dinv_row[row] : 1.0f;
-    const float cr = a.corr != nullptr ? a.corr[row] * (a.dinv_col != nullptr ? a.dinv_col[row] : 1.0f) : 0.0f;
+    const float cr = a.corr != nullptr
+                         ? a.corr[row] * ((a.X != nullptr && a.dinv_col != nullptr) ? a.dinv_col[a.x_row_offset + row] : 1.0f)
+                         : 0.0f;
     const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f4;
     f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
     int k = 0;
@@ -1122,19 +1350,68 @@ __global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
       s += v3;
     }
     for (; k < nseg; ++k) s += *reinterpret_cast<const f32x4*>(pp + k * stride);
+    _Float16 hv[4], lv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int f = f4 + j;
-      if (f >= a.F) break;
-      float y = s[j];
-      if (a.corr != nullptr) y = fmaf(a.w_off, y, cr * a.X[int64_t(row) * a.ldx + f]);
-      else if (a.w_off != 1.0f) y *= a.w_off;
-      if (scale) {
-        y = y * dr;
-        if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+      float y = 0.0f;
+      if (f < a.F) {
+        y = s[j];
+        if (a.addend != nullptr) y += a.addend[int64_t(row) * a.ld_addend + f];
+        if (a.corr != nullptr) {
+          float xv;
+          if (a.X != nullptr) {
+            xv = a.X[(a.x_row_offset + row) * a.ldx + f];
+          } else {
+            const char* pr = a.planes + int64_t(f / kSlice) * a.slice_bytes + (a.x_row_offset + row) * kRowBytes + (f % kSlice) * 2;
+            const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bound_of(a.state, a.Fpad)[f]));
+            xv = (float(*reinterpret_cast<const _Float16*>(pr)) + float(*reinterpret_cast<const _Float16*>(pr + kRowBytes / 2)) * (1.0f / 2048.0f)) *
+                 __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);
+          }
+          y = fmaf(a.w_off, y, cr * xv);
+        } else if (a.w_off != 1.0f) {
+          y *= a.w_off;
+        }
+        if (scale) {
+          y = y * dr;
+          if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+        }
       }
-      a.Y[int64_t(row) * a.ldy + f] = y;
+      if (to_planes) {
+        const uint32_t nb = f < a.F ? (a.adapt ? a.state->amax[f] : bound_of(a.state, a.Fpad)[f]) : 0u;
+        tg_split_one(y, tg_scale(nb), hv[j], lv[j], bad, tiny);
+        const uint32_t yb = __builtin_bit_cast(uint32_t, y) & 0x7FFFFFFFu;
+        if (yb) {
+          if (f < 1024) atomicMax(&smax[f], yb);
+          else atomicMax(&a.state_out->amax[f], yb);
+        }
+      } else if (f < a.F) {
+        a.Y[int64_t(row) * a.ldy + f] = y;
+      }
     }
+    if (to_planes) {
+      char* dst = a.planes_out + int64_t(f4 / kSlice) * a.slice_bytes_out + (a.out_row_offset + row) * kRowBytes + (f4 % kSlice) * 2;
+      auto pack = [](_Float16 x, _Float16 y2) {
+        return uint32_t(__builtin_bit_cast(uint16_t, x)) | (uint32_t(__builtin_bit_cast(uint16_t, y2)) << 16);
+      };
+      *reinterpret_cast<u32x2*>(dst) = u32x2{pack(hv[0], hv[1]), pack(hv[2], hv[3])};
+      *reinterpret_cast<u32x2*>(dst + kRowBytes / 2) = u32x2{pack(lv[0], lv[1]), pack(lv[2], lv[3])};
+    }
+  }
+  if (to_planes) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
+    const bool any_bad = __any(bad);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+      if (tiny) atomicAdd(&a.state_out->tiny, tiny);
+      if (any_bad) atomicOr(&a.state_out->flag, 1u);
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < 1024 && f < a.F; f += blockDim.x)
+      if (smax[f]) {
+        atomicMax(&a.state_out->amax[f], smax[f]);
+        atomicMax(&a.state_out->amax_all, smax[f]);
+      }
   }
 }
 
@@ -1251,7 +1528,7 @@ int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
   pb = w.prim_bytes;
   HIP_TRY(rocprim::exclusive_scan(w.prim, pb, w.lflag, w.lidx, 0u, size_t(w.G), rocprim::plus<uint32_t>(), st));
   hipLaunchKernelGGL(k_tg_totals, dim3(1), dim3(64), 0, st, w.G, w.gstage0, w.step0, w.nseg, w.first, w.lseg, w.slot0,
-                     w.lflag, w.lidx, seg, w.counts);
+                     w.lflag, w.lidx, seg, n_rows, w.counts);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
@@ -1270,7 +1547,7 @@ int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t sta
   TgPlan p = carve_tg_plan(plan, n_rows, stages, steps, items, long_groups);
   if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "tile-group plan buffer too small");
   const unsigned T = 256;
-  HIP_TRY(hipMemcpyAsync(p.counts, w.counts, 64, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p.counts, w.counts, 64, hipMemcpyDeviceToDevice, st));   // counts[7] = n_rows: the SpMM kernel checks its launch against them
   hipLaunchKernelGGL(k_tg_grows, blocks_for(p.G * kRows), dim3(T), 0, st, n_rows, p.G * kRows, w.drow_b, p.grows);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_tg_copy_u32, blocks_for(p.G + 1), dim3(T), 0, st, p.G + 1, w.gstage0, p.gstage0, p.G + 1);
@@ -1308,30 +1585,57 @@ size_t sgnn_tilegroup_planes_bytes(int64_t n_cols, int64_t F) {
   return align_up(size_t(slices) * size_t(n_cols) * kRowBytes + 256);
 }
 
-int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, const float* X, int64_t ldx,
-                             void* planes, size_t planes_bytes, void* state, void* stream) {
+size_t sgnn_tilegroup_state_bytes(int64_t F) {
+  if (F <= 0) return 0;
+  const int64_t Fpad = (F + kSlice - 1) / kSlice * kSlice;
+  return align_up(kStateHead + size_t(2 * Fpad) * sizeof(uint32_t));
+}
+
+int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* state,
+                            void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (n_cols <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty operand");
+  if (n <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty operand");
+  if (!X || !state) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (ldx < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
+  TgState* s = static_cast<TgState*>(state);
+  HIP_TRY(hipMemsetAsync(s, 0, sgnn_tilegroup_state_bytes(F), st));
+  const int64_t per_row = (F + 1) / 2;
+  const unsigned T = unsigned(per_row >= 1024 ? 1024 : (per_row <= 256 ? 256 : (per_row + kWave - 1) / kWave * kWave));
+  // every workgroup ends in one atomic per feature: few workgroups, each with many rows
+  const int64_t quads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(quads < 1024 ? quads : 1024)), dim3(T), 0, st, n, F, scale_row, X, ldx, s);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+int sgnn_tilegroup_planes_f32(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* planes,
+                              int64_t plane_rows, int64_t operand_rows, void* state, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty operand");
   if (!X || !planes || !state) return fail(SGNN_ERR_INVALID, "null pointer");
   if (ldx < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
-  if (planes_bytes < sgnn_tilegroup_planes_bytes(n_cols, F)) return fail(SGNN_ERR_WORKSPACE, "planes buffer too small");
+  if (plane_rows < n || operand_rows < n) return fail(SGNN_ERR_INVALID, "the planes hold fewer rows than are written");
   if (reinterpret_cast<uintptr_t>(planes) % 16) return fail(SGNN_ERR_INVALID, "planes must be 16-byte aligned");
   const int64_t slices = (F + kSlice - 1) / kSlice;
   TgState* s = static_cast<TgState*>(state);
-  HIP_TRY(hipMemsetAsync(s, 0, sizeof(TgState), st));
-  // a thread per pair of features of a row: as many wavefronts as a row (padded to whole slices) needs
-  const int64_t pairs = slices * kSlice / 2;
-  const unsigned T = unsigned(pairs >= 1024 ? 1024 : (pairs <= 256 ? 256 : (pairs + kWave - 1) / kWave * kWave));
-  const unsigned row_blocks = unsigned(n_cols < 16384 ? n_cols : 16384);
-  hipLaunchKernelGGL(k_tg_amax, dim3(row_blocks < 2048 ? row_blocks : 2048), dim3(T), 0, st, n_cols, F, scale_row, X, ldx, s);
+  const int Fpad = int(slices * kSlice);
+  hipLaunchKernelGGL(k_tg_state_init, dim3(unsigned((Fpad + 255) / 256)), dim3(256), 0, st, s,
+                     tg_tiny_limit(operand_rows * F), Fpad);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_tg_split, dim3(row_blocks), dim3(256), 0, st, n_cols, F, slices, scale_row, X, ldx,
-                     static_cast<char*>(planes), s);
-  HIP_TRY(hipGetLastError());
-  const int64_t lim = (n_cols * F) >> 20;
-  hipLaunchKernelGGL(k_tg_finish, dim3(1), dim3(1), 0, st, s, uint32_t(lim > 16 ? lim : 16));
+  const unsigned row_blocks = unsigned(n < 16384 ? n : 16384);
+  hipLaunchKernelGGL(k_tg_split, dim3(row_blocks), dim3(256), 0, st, n, F, slices, scale_row, X, ldx,
+                     static_cast<char*>(planes), plane_rows * int64_t(kRowBytes), s);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
+}
+
+int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, const float* X, int64_t ldx,
+                             void* planes, size_t planes_bytes, void* state, void* stream) {
+  if (n_cols <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty operand");
+  if (planes_bytes < sgnn_tilegroup_planes_bytes(n_cols, F)) return fail(SGNN_ERR_WORKSPACE, "planes buffer too small");
+  int rc = sgnn_tilegroup_amax_f32(n_cols, F, scale_row, X, ldx, state, stream);
+  if (rc != SGNN_OK) return rc;
+  return sgnn_tilegroup_planes_f32(n_cols, F, scale_row, X, ldx, planes, n_cols, n_cols, state, stream);
 }
 
 size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F) {
@@ -1347,14 +1651,26 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
                             void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
                             size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                             const float* vals, const float* dinv_col, const float* X, int64_t ldx,
-                            void* csr_workspace, size_t csr_workspace_bytes, void* stream) {
+                            void* csr_workspace, size_t csr_workspace_bytes, int64_t x_row_offset, const float* addend,
+                            int64_t ld_addend, void* planes_out, int64_t planes_out_rows, int64_t out_row_offset,
+                            void* state_out, int adapt, void* stream) {
   if (n_rows <= 0 || n_cols <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty problem");
-  if (!plan || !planes || !state || !Y) return fail(SGNN_ERR_INVALID, "null pointer");
-  if (ldy < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
+  if (!plan || !planes || !state) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (!planes_out && !Y) return fail(SGNN_ERR_INVALID, "neither Y nor planes_out given");
+  if (!planes_out && ldy < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
   if (epilogue != SGNN_EPI_SCALE_ROW && epilogue != SGNN_EPI_SCALE_ROW2)
     return fail(SGNN_ERR_INVALID, "unknown epilogue mode");
-  if (corr != nullptr && (!X || ldx < F || n_rows != n_cols))
-    return fail(SGNN_ERR_INVALID, "a diagonal correction needs X and a square matrix");
+  if (corr != nullptr && (x_row_offset < 0 || x_row_offset + n_rows > n_cols || (X != nullptr && ldx < F)))
+    return fail(SGNN_ERR_INVALID, "a diagonal correction needs the rows' own operand rows inside the operand");
+  if (addend != nullptr && ld_addend < F) return fail(SGNN_ERR_INVALID, "leading dimension of the addend smaller than F");
+  if (planes_out != nullptr) {
+    if (!state_out) return fail(SGNN_ERR_INVALID, "planes_out needs state_out");
+    if (out_row_offset < 0 || out_row_offset + n_rows > planes_out_rows)
+      return fail(SGNN_ERR_INVALID, "the written rows do not fit planes_out");
+    if (reinterpret_cast<uintptr_t>(planes_out) % 16) return fail(SGNN_ERR_INVALID, "planes_out must be 16-byte aligned");
+    if (rowptr != nullptr) return fail(SGNN_ERR_INVALID, "a hop that writes planes has no fall-back of its own: the chain's caller launches it");
+    if (planes_out == planes) return fail(SGNN_ERR_INVALID, "planes_out must not be the operand");
+  }
   if (stages <= 0 || steps <= 0 || items <= 0 || partial_slots < 0 || long_groups < 0)
     return fail(SGNN_ERR_INVALID, "counts do not match the plan");
   TgPlan p = carve_tg_plan(const_cast<void*>(plan), n_rows, stages, steps, items, long_groups);
@@ -1366,39 +1682,48 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   const int64_t slices = (F + kSlice - 1) / kSlice;
   if (slices * items >= (int64_t(1) << 31)) return fail(SGNN_ERR_INVALID, "too many workgroups for one launch");
   TgArgs a{};
+  a.plan_counts = p.counts;
   a.grows = p.grows; a.stage_col = p.stage_col; a.step0 = p.step0;
   a.step_slots = p.step_slots; a.step_bits = p.step_bits;
   a.item_group = p.item_group; a.item_s0 = p.item_s0; a.item_s1 = p.item_s1; a.item_out = p.item_out;
   a.long_group = p.long_group; a.long_slot = p.long_slot; a.long_nseg = p.long_nseg;
   a.planes = static_cast<const char*>(planes);
-  a.state = static_cast<const TgState*>(state);
+  a.state = static_cast<TgState*>(state);
   a.queue = &static_cast<TgState*>(state)->queue;
   a.dinv_row = dinv_row; a.Y = Y; a.partial = static_cast<float*>(workspace);
   a.corr = corr; a.X = X; a.dinv_col = dinv_col; a.ldx = ldx;
+  a.addend = addend; a.ld_addend = ld_addend;
+  a.planes_out = static_cast<char*>(planes_out);
+  a.state_out = static_cast<TgState*>(state_out);
+  a.slice_bytes_out = planes_out_rows * int64_t(kRowBytes);
+  a.x_row_offset = x_row_offset; a.out_row_offset = out_row_offset; a.n_rows = n_rows;
   a.ldy = ldy; a.slice_bytes = n_cols * kRowBytes;
   a.items = int32_t(items); a.n_long = int32_t(long_groups);
+  a.stages = int32_t(stages); a.steps = int32_t(steps);
   a.F = int32_t(F); a.Fpad = int32_t(slices * kSlice); a.epilogue = epilogue; a.w_off = w_off;
   a.mode = g_tg_mode;
   a.slices = int32_t(slices);
+  a.tiny_limit_out = tg_tiny_limit(planes_out_rows * F);
+  a.adapt = adapt ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // per device: the attribute belongs to the device's copy of the kernel, and the number of
-  // workgroups to the device's CUs (a process may drive more than one GPU)
-  static bool attr_set[64] = {};
-  static int cus_of[64] = {};
+  // workgroups to the device's CUs (a process may drive more than one GPU, from more than one thread)
+  static std::atomic<int> cus_of[64];
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return fail(SGNN_ERR_INVALID, "device ordinal out of range");
-  if (!attr_set[dev]) {
+  int n_cus = cus_of[dev].load(std::memory_order_acquire);
+  if (n_cus == 0) {   // (two threads may both get here: they set the same attribute and store the same count)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tg_spmm),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    HIP_TRY(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus_of[dev] <= 0) cus_of[dev] = 256;
-    attr_set[dev] = true;
+    HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cus <= 0) n_cus = 256;
+    cus_of[dev].store(n_cus, std::memory_order_release);
   }
-  // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
-  const int n_cus = cus_of[dev];
-  sgnn::kernel_timer_begin(st);
+  if (planes_out != nullptr) HIP_TRY(hipMemsetAsync(state_out, 0, sgnn_tilegroup_state_bytes(F), st));
   HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st));
+  // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
+  sgnn::kernel_timer_begin(st);
   const int64_t wgs = (items * slices < n_cus || (a.mode & 128)) ? items * slices : n_cus;
   hipLaunchKernelGGL(k_tg_spmm, dim3(unsigned(wgs)), dim3(kWaves * kWave), kLdsBytes, st, a);
   HIP_TRY(hipGetLastError());
@@ -1410,9 +1735,60 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   if (rowptr != nullptr) {
     // fall-back for an X the planes cannot represent: the plain CSR kernel on the original
     // operand, behind the same flag (its kernels return at once while the flag is 0)
-    if (!colidx || !X) return fail(SGNN_ERR_INVALID, "null pointer");
+    if (!colidx || !X || !Y) return fail(SGNN_ERR_INVALID, "null pointer");
+    if (addend != nullptr) return fail(SGNN_ERR_INVALID, "a launch with an addend has no fall-back");
     return spmm_csr_guarded(n_rows, n_cols, nnz, F, rowptr, colidx, vals, dinv_row, dinv_col, X, ldx, Y, ldy, epilogue,
                             csr_workspace, csr_workspace_bytes, &static_cast<const TgState*>(state)->flag, st);
+  }
+  return SGNN_OK;
+}
+
+int sgnn_tilegroup_chain_f32(int K, int64_t n, int64_t F, const void* plan, size_t plan_bytes, int64_t stages,
+                             int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups, const float* dinv,
+                             float w_off, const float* corr, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                             void* planes_a, void* planes_b, size_t planes_bytes, void* states, size_t states_bytes,
+                             void* workspace, size_t workspace_bytes, int64_t nnz, const int32_t* rowptr,
+                             const int32_t* colidx, const float* vals, void* csr_workspace, size_t csr_workspace_bytes,
+                             void* stream) {
+  if (K < 1) return fail(SGNN_ERR_INVALID, "K must be at least 1");
+  if (n <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty problem");
+  if (!dinv || !X || !Y || !planes_a || !states || !rowptr || !colidx) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (K > 1 && !planes_b) return fail(SGNN_ERR_INVALID, "a second planes buffer is required when K > 1");
+  const size_t sb = sgnn_tilegroup_state_bytes(F);
+  if (states_bytes < sb * size_t(K)) return fail(SGNN_ERR_WORKSPACE, "one state block per hop is required");
+  if (planes_bytes < sgnn_tilegroup_planes_bytes(n, F)) return fail(SGNN_ERR_WORKSPACE, "planes buffer too small");
+  char* sp = static_cast<char*>(states);
+  // operand 0: utils.py:93 applied by the split pass
+  int rc = sgnn_tilegroup_split_f32(n, F, dinv, X, ldx, planes_a, planes_bytes, sp, stream);
+  if (rc != SGNN_OK) return rc;
+  for (int h = 0; h < K; ++h) {
+    const bool last = h == K - 1;
+    void* src = (h % 2 == 0) ? planes_a : planes_b;
+    void* dst = (h % 2 == 0) ? planes_b : planes_a;
+    rc = sgnn_spmm_tilegroup_f32(n, n, F, plan, plan_bytes, stages, steps, items, partial_slots, long_groups, dinv,
+                                 w_off, corr, src, planes_bytes, sp + sb * h, last ? Y : nullptr, ldy,
+                                 last ? SGNN_EPI_SCALE_ROW : SGNN_EPI_SCALE_ROW2, workspace, workspace_bytes, nnz, nullptr,
+                                 nullptr, nullptr, h == 0 ? dinv : nullptr, h == 0 ? X : nullptr, ldx, nullptr, 0, 0,
+                                 nullptr, 0, last ? nullptr : dst, n, 0, last ? nullptr : sp + sb * (h + 1), 1, stream);
+    if (rc != SGNN_OK) return rc;
+  }
+  // Fall-back, behind the last operand's flag (a refusal anywhere in the chain is handed down to
+  // it): the whole chain again through the plain CSR kernel on the fp32 operand.  Its
+  // intermediates live in the planes' memory, which is dead once the flag is up; while the flag
+  // is 0 the guarded kernels return at once and touch nothing.
+  const uint32_t* guard = &reinterpret_cast<const TgState*>(sp + sb * (K - 1))->flag;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float* src = X;
+  int64_t lds = ldx;
+  for (int h = 0; h < K; ++h) {
+    const bool last = h == K - 1;
+    float* dst = last ? Y : static_cast<float*>((h % 2 == 0) ? planes_a : planes_b);
+    const int64_t ldd = last ? ldy : F;
+    rc = spmm_csr_guarded(n, n, nnz, F, rowptr, colidx, vals, dinv, h == 0 ? dinv : nullptr, src, lds, dst, ldd,
+                          last ? SGNN_EPI_SCALE_ROW : SGNN_EPI_SCALE_ROW2, csr_workspace, csr_workspace_bytes, guard, st);
+    if (rc != SGNN_OK) return rc;
+    src = dst;
+    lds = ldd;
   }
   return SGNN_OK;
 }

@@ -18,6 +18,19 @@ import torch
 from . import _lib
 
 
+def _keep(cache, key, value, limit=4):
+    """Put ``value`` under ``key`` in a small insertion-ordered cache, dropping the oldest
+    entries beyond ``limit``.  The per-width buffers (planes, partial rows, workspaces) are
+    kept this way: a stack of layers alternates between a few widths on one adjacency
+    (Reddit: 602 and 128), and a single-entry cache would reallocate and clear half a
+    gigabyte on every call."""
+    cache.pop(key, None)
+    cache[key] = value
+    while len(cache) > limit:
+        cache.pop(next(iter(cache)))
+    return value
+
+
 def _as_index_tensor(a, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.int64).contiguous()
@@ -89,29 +102,63 @@ def tilegroup_build(n_rows, n_cols, nnz, rowptr, colidx, device, auto=True):
                 n_long=n_long, bufs={})
 
 
-def tilegroup_hop(plan, n_rows, n_cols, nnz, rowptr, colidx, vals, F, X, ldx, Y, ldy, dinv_row, split_scale, w_off, corr,
-                  epilogue, csr_ws, device):
-    """One hop through the tile-group kernel: split X (times ``split_scale`` per row if given) into
-    fp16 planes, multiply; the plain CSR kernel stands behind it for operands the planes cannot
-    represent.  The per-width buffers (planes, partial rows, state words) live in ``plan["bufs"]``."""
+def tilegroup_buffers(plan, n_cols, F, device, hops=1):
+    """Per-width buffers of the tile-group kernel, kept in ``plan["bufs"]``: two sets of operand
+    planes (the second only once a chain needs it), the partial rows of split groups, and one
+    block of state words per hop (flag, counters, per-feature scales)."""
     lib = _lib.load()
     bufs = plan["bufs"].get(F)
     if bufs is None:
         pl_bytes = lib.sgnn_tilegroup_planes_bytes(n_cols, F)
         ws_bytes = lib.sgnn_spmm_tilegroup_workspace_bytes(plan["slots"], F)
-        bufs = dict(planes=torch.empty(pl_bytes, dtype=torch.uint8, device=device), pl_bytes=pl_bytes,
+        sb = lib.sgnn_tilegroup_state_bytes(F)
+        bufs = dict(planes=torch.empty(pl_bytes, dtype=torch.uint8, device=device), planes_b=None, pl_bytes=pl_bytes,
                     ws=torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=device),
-                    state=torch.zeros(64, dtype=torch.int32, device=device))
-        plan["bufs"] = {F: bufs}
+                    state_bytes=sb, states=torch.zeros((1, sb // 4), dtype=torch.int32, device=device))
+        bufs["state"] = bufs["states"][0]
+        _keep(plan["bufs"], F, bufs)
+    if hops > 1 and bufs["planes_b"] is None:
+        bufs["planes_b"] = torch.empty(bufs["pl_bytes"], dtype=torch.uint8, device=device)
+    if bufs["states"].shape[0] < hops:
+        bufs["states"] = torch.zeros((hops, bufs["state_bytes"] // 4), dtype=torch.int32, device=device)
+    # the flag and the counters the tests and tools look at: those of the operand of the last hop run
+    bufs["state"] = bufs["states"][hops - 1]
+    return bufs
+
+
+def tilegroup_hop(plan, n_rows, n_cols, nnz, rowptr, colidx, vals, F, X, ldx, Y, ldy, dinv_row, split_scale, w_off, corr,
+                  epilogue, csr_ws, device):
+    """One hop through the tile-group kernel: split X (times ``split_scale`` per row if given) into
+    fp16 planes, multiply; the plain CSR kernel stands behind it for operands the planes cannot
+    represent.  The per-width buffers live in ``plan["bufs"]``."""
+    lib = _lib.load()
+    bufs = tilegroup_buffers(plan, n_cols, F, device)
     st = _lib.current_stream(device)
+    state = bufs["states"][0]
+    bufs["state"] = state
     _lib.check(lib.sgnn_tilegroup_split_f32(n_cols, F, _lib.ptr(split_scale), _lib.ptr(X), ldx,
-                                            _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), st))
+                                            _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(state), st))
     _lib.check(lib.sgnn_spmm_tilegroup_f32(
         n_rows, n_cols, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"],
         plan["slots"], plan["n_long"], _lib.ptr(dinv_row), float(w_off), _lib.ptr(corr),
-        _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(bufs["state"]), _lib.ptr(Y), ldy, int(epilogue),
+        _lib.ptr(bufs["planes"]), bufs["pl_bytes"], _lib.ptr(state), _lib.ptr(Y), ldy, int(epilogue),
         _lib.ptr(bufs["ws"]), bufs["ws"].numel(), nnz, _lib.ptr(rowptr), _lib.ptr(colidx),
-        _lib.ptr(vals), _lib.ptr(split_scale), _lib.ptr(X), ldx, _lib.ptr(csr_ws), csr_ws.numel(), st))
+        _lib.ptr(vals), _lib.ptr(split_scale), _lib.ptr(X), ldx, _lib.ptr(csr_ws), csr_ws.numel(),
+        0, None, 0, None, 0, 0, None, 0, st))
+    return bufs
+
+
+def tilegroup_chain(plan, n, nnz, rowptr, colidx, vals, F, X, ldx, Y, ldy, dinv, w_off, corr, order, csr_ws, device):
+    """``A_hat^order . X`` through the tile-group kernel (``sgnn_tilegroup_chain_f32``): X is split
+    once, every hop but the last writes the next hop's operand planes from its epilogue."""
+    lib = _lib.load()
+    bufs = tilegroup_buffers(plan, n, F, device, hops=order)
+    _lib.check(lib.sgnn_tilegroup_chain_f32(
+        order, n, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"], plan["slots"],
+        plan["n_long"], _lib.ptr(dinv), float(w_off), _lib.ptr(corr), _lib.ptr(X), ldx, _lib.ptr(Y), ldy,
+        _lib.ptr(bufs["planes"]), _lib.ptr(bufs["planes_b"]), bufs["pl_bytes"], _lib.ptr(bufs["states"]),
+        bufs["states"].numel() * 4, _lib.ptr(bufs["ws"]), bufs["ws"].numel(), nnz, _lib.ptr(rowptr), _lib.ptr(colidx),
+        _lib.ptr(vals), _lib.ptr(csr_ws), csr_ws.numel(), _lib.current_stream(device)))
     return bufs
 
 
@@ -264,7 +311,7 @@ class NormAdj:
         if ws is None:
             nbytes = _lib.load().sgnn_spmm_workspace_bytes(self.n, self.nnz, F)
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-            self._ws = {F: ws}            # keep one: callers alternate between few widths
+            _keep(self._ws, F, ws)        # callers alternate between few widths
         return ws
 
     def _rowgroup_plan(self, F):
@@ -324,14 +371,14 @@ class NormAdj:
         bufs = tilegroup_hop(plan, self.n, self.n, self.nnz, self.rowptr, self.colidx, self._vals, F, X, ldx, Y, ldy,
                              self.dinv if scale_rows else None, self.dinv if scale_cols else None, self.w_off,
                              self.corr, epilogue, self._workspace(F), self.device)
-        self._tg_bufs = {F: bufs}
+        _keep(self._tg_bufs, F, bufs)
 
     def _rowgroup_ws(self, plan, F):
         ws = plan["ws"].get(F)
         if ws is None:
             nbytes = _lib.load().sgnn_spmm_rowgroup_workspace_bytes(plan["slots"], plan["R"], F)
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-            plan["ws"] = {F: ws}
+            _keep(plan["ws"], F, ws)
         return ws
 
     def _folds_col_scale(self, plan, ldx):
@@ -437,16 +484,13 @@ class NormAdj:
                 return Y
             tg = self._tilegroup_plan(F)
             if tg is not None:
-                # tile-group kernel: the split pass applies utils.py:93 on the first hop; later
-                # hops read what the previous epilogue already scaled twice
-                src, lds = X, (X.stride(0) if X.shape[0] > 1 else F)
-                spare = [torch.empty((self.n, F), dtype=torch.float32, device=self.device) for _ in range(min(order - 1, 2))]
-                for h in range(order):
-                    last = h == order - 1
-                    dst = Y if last else spare[h % 2]
-                    self._tilegroup_hop(tg, src, lds, dst, F, F, True, h == 0,
-                                        _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2)
-                    src, lds = dst, F
+                # tile-group kernel: X is split into fp16 planes once (the split applies
+                # utils.py:93); every hop but the last writes the next hop's planes from its
+                # epilogue, so no intermediate exists as fp32 or is measured and split again
+                bufs = tilegroup_chain(tg, self.n, self.nnz, self.rowptr, self.colidx, self._vals, F, X,
+                                       X.stride(0) if X.shape[0] > 1 else F, Y, F, self.dinv, self.w_off, self.corr,
+                                       order, self._workspace(F), self.device)
+                _keep(self._tg_bufs, F, bufs)
                 return Y
             if self._rowgroup_plan(F) is None:
                 # plain CSR kernel: the library's own K-hop chain

@@ -81,6 +81,45 @@ def test_reddit_shape_full_size_properties(gpu_device):
     assert float((chain - hops).norm() / hops.norm()) <= TOL
 
 
+def test_reddit_shape_weight2_full_size_three_kernels_agree(gpu_device):
+    """The Reddit configuration as the reference loads it: ``adj + adj.T`` makes every stored
+    entry 2.0 (data_loader.py:75), ``A + I`` then puts 1.0 on the diagonal (utils.py:86) -- the
+    kernel instances with the diagonal correction, at the benchmark's size, widths 602 and 41:
+    tile-group, row-group and plain CSR agree normwise and element by element against
+    ``|A_hat| |X|``, and the weighted fixed point ``A_hat D^1/2 1 = D^1/2 1`` holds."""
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import SHAPES, rmat_undirected_device
+    dev = gpu_device
+    n, E, _ = SHAPES["reddit"]
+    row, col = rmat_undirected_device(n, E, seed=1, device=dev)
+    val = torch.full((row.numel(),), 2.0, device=dev)
+    adj = NormAdj.from_coo(row, col, val, n, dev)
+    del row, col, val
+    assert adj.w_off == 2.0 and adj.corr is not None and not adj.unit_weights
+    counts = (adj.rowptr[1:] - adj.rowptr[:-1]).float()
+    assert torch.equal(adj.deg, 2.0 * (counts - 1.0) + 1.0)          # weighted row sum, exact in fp32
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    for F in (602, 41):
+        X = torch.randn(n, F, device=dev, generator=g)
+        adj.use_tilegroup, adj.use_rowgroup = None, True
+        Y_tg = adj.propagate(X, 1)
+        assert adj._tg, "tile-group plan was not used"
+        assert int(adj._tg_bufs[F]["state"][1].item()) == 0
+        adj.use_tilegroup = False
+        Y_rg = adj.propagate(X, 1)
+        adj.use_rowgroup = False
+        Y_csr = adj.propagate(X, 1)
+        scale = adj.propagate(X.abs(), 1)
+        for Y in (Y_rg, Y_tg):
+            assert float((Y - Y_csr).norm() / Y_csr.norm()) <= TOL
+            assert float(((Y - Y_csr).abs() / scale.clamp_min(1e-30)).max()) <= TOL
+        del X, Y_tg, Y_rg, Y_csr, scale
+    adj.use_tilegroup, adj.use_rowgroup = None, True
+    s = adj.deg.sqrt()
+    fixed = adj.propagate(s[:, None].expand(n, 64).contiguous(), 1)
+    assert float(((fixed - s[:, None]).abs() / s[:, None]).max()) <= TOL
+
+
 @pytest.mark.parametrize("rowgroup", [True, False])
 def test_x_larger_than_4gib(gpu_device, rowgroup):
     """Rows of X 16 KiB apart: the matrix spans 4.9 GB, so a row's byte offset does

@@ -177,3 +177,101 @@ def test_kernel_timer_counts_the_main_kernel_of_every_path(gpu_device):
         lib.sgnn_tune_set(b"time_kernel", 0)
     adj.propagate(X, 1)
     assert _lib.kernel_time_ms() == (0.0, 0)
+
+
+@pytest.mark.parametrize("weight", [None, 2.0])
+def test_chain_writes_the_next_operand_from_the_epilogue(gpu_device, weight):
+    """K = 3 as one chain (utils.py:91-96): X is split once and the two intermediates exist only as
+    the fp16 planes the hop before wrote from its epilogue, at scales derived from bounds (a row
+    of D^-1 (A+I) sums to one).  It must equal three single hops -- each of which measures and
+    splits its fp32 operand -- element by element, and ordinary data must never raise the flag."""
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import rmat_undirected_device
+    dev = gpu_device
+    n, F = 30_000, 200
+    row, col = rmat_undirected_device(n, 3_000_000, seed=12, device=dev)
+    val = None if weight is None else torch.full((row.numel(),), weight, device=dev)
+    adj = NormAdj.from_coo(row, col, val, n, dev)
+    adj.use_tilegroup = True
+    g = torch.Generator(device=dev); g.manual_seed(13)
+    X = torch.randn(n, F, device=dev, generator=g)
+    chain = adj.propagate(X, 3)
+    torch.cuda.synchronize()
+    states = adj._tg_bufs[F]["states"]
+    assert states.shape[0] >= 3 and [int(states[k, 1].item()) for k in range(3)] == [0, 0, 0]
+    hops = X
+    for _ in range(3):
+        hops = adj.spmm(hops)
+        assert int(adj._tg_bufs[F]["state"][1].item()) == 0
+    adj.use_tilegroup, adj.use_rowgroup = False, False
+    plain = adj.propagate(X, 3)
+    scale = adj.propagate(X.abs(), 3)
+    for other in (hops, plain):
+        assert float((chain - other).norm() / other.norm()) <= TOL
+        assert float(((chain - other).abs() / scale.clamp_min(1e-30)).max()) <= TOL
+    # the same chain twice: same bits (the per-feature maxima are gathered with atomics, the sums are not)
+    adj.use_tilegroup, adj.use_rowgroup = True, True
+    assert torch.equal(adj.propagate(X, 3), chain)
+
+
+def test_chain_refused_anywhere_equals_the_plain_chain(gpu_device):
+    """A chain whose first operand the planes cannot hold (an infinite element), and one that
+    only a later hop refuses (the first operand's columns are fine, but one row is so large that
+    after a hop most of every column sits 2^40 below its bound): the flag travels down the chain
+    and the result is the plain CSR chain's, bit for bit."""
+    adj, r, c, v = _graph(4000, 80_000, seed=31, dev=gpu_device)
+    F = 96
+    g = torch.Generator(device=gpu_device); g.manual_seed(32)
+    base = torch.randn(4000, F, device=gpu_device, generator=g)
+    for kind in ("inf", "late"):
+        X = base.clone()
+        if kind == "inf":
+            X[7, 3] = float("inf")
+        else:
+            X[11] *= 2.0 ** 45
+        adj.use_tilegroup, adj.use_rowgroup = True, True
+        Y = adj.propagate(X, 3)
+        torch.cuda.synchronize()
+        states = adj._tg_bufs[F]["states"]
+        flags = [int(states[k, 1].item()) for k in range(3)]
+        assert flags[2] != 0, f"{kind}: the last operand's flag must be up"
+        if kind == "inf":
+            assert flags[0] != 0
+        adj.use_tilegroup, adj.use_rowgroup = False, False
+        Y_ref = adj.propagate(X, 3)
+        assert torch.equal(torch.isfinite(Y), torch.isfinite(Y_ref))
+        fin = torch.isfinite(Y_ref)
+        assert torch.equal(Y[fin], Y_ref[fin])
+
+
+def test_launch_counts_that_do_not_match_the_plan_raise_the_flag(gpu_device):
+    """The C ABI takes the plan's counts from the caller.  A tuple that differs from what the plan
+    was filled with must not be used to carve the plan: the kernel compares it with the counts the
+    plan records, raises the flag (bit 4) and leaves the result to the fall-back."""
+    from sgnn_amd import _lib
+    from sgnn_amd.norm_adj import tilegroup_buffers
+    lib = _lib.load()
+    adj, r, c, v = _graph(3000, 40_000, seed=41, dev=gpu_device)
+    F = 128
+    X = torch.randn(3000, F, device=gpu_device)
+    Y_good = adj.spmm(X)
+    plan = adj._tg
+    bufs = tilegroup_buffers(plan, adj.n, F, gpu_device)
+    st = _lib.current_stream(gpu_device)
+    state = bufs["states"][0]
+    _lib.check(lib.sgnn_tilegroup_split_f32(adj.n, F, _lib.ptr(adj.dinv), _lib.ptr(X), F, _lib.ptr(bufs["planes"]),
+                                            bufs["pl_bytes"], _lib.ptr(state), st))
+    Y = torch.full((3000, F), 7.0, device=gpu_device)
+    ws = adj._workspace(F)
+    # one step fewer than the plan holds: every later sub-array would be read at a shifted offset
+    _lib.check(lib.sgnn_spmm_tilegroup_f32(
+        adj.n, adj.n, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"] - 1, plan["items"],
+        plan["slots"], plan["n_long"], _lib.ptr(adj.dinv), 1.0, None, _lib.ptr(bufs["planes"]), bufs["pl_bytes"],
+        _lib.ptr(state), _lib.ptr(Y), F, _lib.EPI_SCALE_ROW, _lib.ptr(bufs["ws"]), bufs["ws"].numel(), adj.nnz,
+        _lib.ptr(adj.rowptr), _lib.ptr(adj.colidx), None, _lib.ptr(adj.dinv), _lib.ptr(X), F, _lib.ptr(ws), ws.numel(),
+        0, None, 0, None, 0, 0, None, 0, st))
+    torch.cuda.synchronize()
+    assert int(state[1].item()) & 4
+    adj.use_tilegroup, adj.use_rowgroup = False, False
+    assert torch.equal(Y, adj.spmm(X))                   # the fall-back computed it
+    assert float((Y - Y_good).norm() / Y_good.norm()) <= TOL
