@@ -1151,7 +1151,9 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
               y = y * dr;
               if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
             }
-            if (row < 0) y = 0.0f;
+            // rows that do not exist, and features past F (the correction read a clamped feature
+            // for them): zero, as the planes' padding must be
+            if (row < 0 || slice * kSlice + int(fl) >= a.F) y = 0.0f;
           }
           if (to_planes) {
             _Float16 hv, lv;
