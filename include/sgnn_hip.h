@@ -196,15 +196,17 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  * X through LDS; the sums run on the matrix cores (v_mfma_f32_32x32x16_f16, fp32
  * accumulation) over X split into two fp16 planes, hi + lo / 2048, with one power-of-two
  * scale per feature column (columns never mix in A . X).  What the planes do to the
- * arithmetic, as enforced on the device: every element is reproduced to 2^-21 relative or
- * better (checked element by element when the planes are written; typically 2^-22); an
- * operand with a non-finite element, an element the planes miss by more, or more than
- * max(16, elements / 2^20) nonzero elements so far below their column's largest magnitude
- * (2^-33) that fewer than 17 of their bits survive, is refused: a device flag goes up, the
- * matrix-core kernel does nothing, and the plain CSR kernel launched behind it computes the
- * result from the fp32 operand (bit-identical to sgnn_spmm_csr_f32), with no host
- * synchronisation.  Accepted operands give results that agree with sgnn_spmm_csr_f32 to
- * 2^-20 of |A||X| element by element (summation order included) and are reproducible run to run.
+ * arithmetic, as enforced on the device: an element within 2^29 of its column's largest
+ * magnitude is reproduced to 2^-22 relative, a smaller one to 2^-50 of that largest
+ * magnitude; an operand with a non-finite element, an element of at least twice its
+ * column's bound, or more than max(16, elements / 2^20) nonzero elements so far below their
+ * column's largest magnitude (2^-33) that fewer than 17 of their bits survive, is refused:
+ * a device flag goes up, the matrix-core kernel does nothing, and the plain CSR kernel
+ * launched behind it computes the result from the fp32 operand (bit-identical to
+ * sgnn_spmm_csr_f32), with no host synchronisation.  Accepted operands give results as far
+ * from the exact product as sgnn_spmm_csr_f32's plus at most 2^-21 of |A||X| per hop,
+ * element by element (on ordinary data the two kernels agree to 2^-20 of |A||X|), and are
+ * reproducible run to run.
  *
  * Plan (once per matrix), two steps because its size depends on the matrix:
  *   sgnn_tilegroup_analyze  sorts and counts into `workspace`

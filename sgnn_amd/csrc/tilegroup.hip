@@ -552,19 +552,23 @@ __device__ __forceinline__ float tg_scale(uint32_t amax_bits) {
   return __builtin_bit_cast(float, uint32_t(s + 127) << 23);
 }
 
-// One element into its two planes: xs = hi + lo / 2048 to 2^-22 of xs (fp16 carries 11 bits, the
-// remainder times 2048 another 11) down to the spacing of the lo plane's subnormals, 2^-35.
-// `bad`: the pair does not reproduce xs to 2^-21 (non-finite values included: `!(<=)` catches NaN);
-// `tiny`: a nonzero element so far below its feature's bound that fewer than 17 bits survive.
-__device__ __forceinline__ void tg_split_one(float xv, float scale, _Float16& h, _Float16& l, bool& bad, uint32_t& tiny) {
+// One element into its two planes: xs = hi + lo / 2048.  For |xs| in [2^-14, 2^16) the pair
+// reproduces xs to 2^-22 relative (fp16 carries 11 bits, the exact remainder times 2048 another
+// 11); below, to the spacing of the lo plane's subnormals, 2^-35.  What can go wrong is therefore
+// decided by the element's magnitude alone and is checked on the maxima the writers keep anyway:
+// a non-finite element or one beyond twice its feature's bound (hi would overflow) raises the
+// flag through tg_beyond(); `tiny` counts the nonzero elements so far below the bound
+// (|xs| < 2^-19) that fewer than 17 of their bits survive.
+__device__ __forceinline__ void tg_split_one(float xv, float scale, _Float16& h, _Float16& l, uint32_t& tiny) {
   const float xs = xv * scale;
   h = _Float16(xs);
-  const float r = xs - float(h);
-  l = _Float16(r * 2048.0f);
-  const float back = float(h) + float(l) * (1.0f / 2048.0f);
-  const float ax = __builtin_fabsf(xs);
-  bad |= !(__builtin_fabsf(xs - back) <= __builtin_fmaxf(ax * 4.8e-7f, 3.0e-11f));
-  tiny += (xv != 0.0f && ax < 1.9e-6f) ? 1u : 0u;   // below 2^-19 (or flushed to 0)
+  l = _Float16((xs - float(h)) * 2048.0f);
+  tiny += (xv != 0.0f && __builtin_fabsf(xs) < 1.9e-6f) ? 1u : 0u;
+}
+// a largest magnitude (bit pattern) the planes cannot hold at the scale derived from `bound`:
+// non-finite, or at least twice the bound (the scale leaves one binade of headroom below fp16's largest)
+__device__ __forceinline__ bool tg_beyond(uint32_t max_bits, uint32_t bound_bits) {
+  return max_bits >= 0x7F800000u || max_bits >= bound_bits + (1u << 23);
 }
 
 // planes[slice][node] = 128 halfs hi | 128 halfs lo of (scale_row[node] * X[node, slice]) * scale[feature].
@@ -578,7 +582,6 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
                                                   TgState* __restrict__ state) {
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
   const int64_t Fpad = n_slices * kSlice;
-  bool bad = false;
   uint32_t tiny = 0;
   // (one node per pass and set of threads: the 4-byte stores bound this kernel, more loads in
   // flight do not help; a node of one or two slices needs 64 or 128 threads, so the workgroup
@@ -609,8 +612,8 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
         if (f + 1 < F) x[1] = row[f + 1];
       }
       _Float16 hi[2], lo[2];
-      tg_split_one(x[0] * sr, s0, hi[0], lo[0], bad, tiny);   // x * sr: the reference's scaling (utils.py:93), fp32
-      tg_split_one(x[1] * sr, s1, hi[1], lo[1], bad, tiny);
+      tg_split_one(x[0] * sr, s0, hi[0], lo[0], tiny);   // x * sr: the reference's scaling (utils.py:93), fp32
+      tg_split_one(x[1] * sr, s1, hi[1], lo[1], tiny);
       const int64_t slice = f / kSlice;
       const int within = int(f % kSlice);
       char* dst = planes + slice * slice_stride + node * kRowBytes + within * 2;
@@ -631,11 +634,7 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
   // one atomic per wavefront
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
-  const bool any_bad = __any(bad);
-  if ((threadIdx.x & (kWave - 1)) == 0) {
-    if (tiny) atomicAdd(&state->tiny, tiny);
-    if (any_bad) atomicOr(&state->flag, 1u);
-  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && tiny) atomicAdd(&state->tiny, tiny);
 }
 
 // A continuous distribution leaves a handful of tiny elements among 10^8 (they change a sum
@@ -650,7 +649,10 @@ __host__ __device__ inline uint32_t tg_tiny_limit(int64_t elements) {
 __global__ void k_tg_state_init(TgState* __restrict__ state, uint32_t tiny_limit, int Fpad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) state->tiny_limit = tiny_limit;
-  if (i < Fpad) bound_of(state, Fpad)[i] = state->amax[i];
+  if (i < Fpad) {
+    bound_of(state, Fpad)[i] = state->amax[i];
+    if (state->amax[i] >= 0x7F800000u) atomicOr(&state->flag, 1u);   // a non-finite element
+  }
 }
 
 // cycle counts of a diagnostic run (mode bit 16): kernel, waits for a stage, issue of the next
@@ -1074,7 +1076,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   // read here: that measured maximum (or, where ranks would have to agree on it first, the
   // older bound) is the next operand's bound.
   float inv_sc[NT], sc_out[NT];
-  uint32_t mx[NT];
+  uint32_t mx[NT], nxt_b[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int f = slice * kSlice + nt * 32 + (lane & 31);
@@ -1083,9 +1085,9 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
     inv_sc[nt] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);   // 1 / scale, exact: a power of two
     sc_out[nt] = tg_scale(nxt);
+    nxt_b[nt] = nxt;
     mx[nt] = 0;
   }
-  bool bad = false;
   uint32_t tiny = 0;
   __builtin_amdgcn_s_barrier();   // the ring is no longer read
   const uint32_t stg = uint32_t(kTableBytes) + uint32_t(w) * uint32_t(kStageOutBytes);
@@ -1157,7 +1159,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
           }
           if (to_planes) {
             _Float16 hv, lv;
-            tg_split_one(y, sc_out[nt], hv, lv, bad, tiny);
+            tg_split_one(y, sc_out[nt], hv, lv, tiny);
             const uint32_t yb = __builtin_bit_cast(uint32_t, y) & 0x7FFFFFFFu;
             mx[nt] = yb > mx[nt] ? yb : mx[nt];
             *lds<_Float16>(stg + rl * uint32_t(kRowBytes) + fl * 2u) = hv;
@@ -1208,6 +1210,9 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     // it, and each feature's largest magnitude (the bound of the hop after next)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
+    bool bad = false;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bad |= tg_beyond(mx[nt], nxt_b[nt]);
     const bool any_bad = __any(bad);
     if (lane == 0) {
       if (tiny) atomicAdd(&a.state_out->tiny, tiny);
@@ -1224,7 +1229,6 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
       const uint32_t m = *lds<uint32_t>(uint32_t(kAmaxOff) + uint32_t(tid) * 4u);
       if (m) {
         atomicMax(&a.state_out->amax[slice * kSlice + tid], m);
-        atomicMax(&a.state_out->amax_all, m);
         *lds<uint32_t>(uint32_t(kAmaxOff) + uint32_t(tid) * 4u) = 0u;
       }
     }
@@ -1307,100 +1311,135 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
 }
 
 // rows of a group cut into several items: add the items' partial rows in order, then the row epilogue
-__global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
+// The launch's workgroup size is a multiple of the (row, four features) pairs of one row
+// (tg_combine_threads), so a thread keeps the same four features for every row it visits.
+__host__ __device__ inline int tg_combine_quads(int F, int Fpad, bool to_planes) { return ((to_planes ? Fpad : F) + 3) / 4; }
+inline unsigned tg_combine_threads(int quads) {
+  if (quads >= 1024) return 1024;
+  const int rows = 256 / quads > 0 ? 256 / quads : 1;
+  const int t = quads * rows;
+  return unsigned(t < 64 ? 64 : t);
+}
+
+__global__ __launch_bounds__(1024) void k_tg_combine(TgArgs a) {
   if (tg_refused(a, false)) return;
-  __shared__ uint32_t smax[1024];   // per-feature maxima of the rows written as planes (widths beyond 1024 go straight to memory)
   const bool to_planes = a.planes_out != nullptr;
+  __shared__ uint32_t smax[4096];   // rows_par > 1 means at most 512 features
   if (to_planes) {
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) smax[i] = 0;
+    for (int i = threadIdx.x; i < 4096 && i < a.F; i += blockDim.x) smax[i] = 0;
     __syncthreads();
   }
   const int li = blockIdx.x;
   const int g = a.long_group[li], slot = a.long_slot[li], nseg = a.long_nseg[li];
   const int64_t stride = int64_t(kRows) * a.Fpad;
-  // A workgroup takes the rows blockIdx.y, blockIdx.y + gridDim.y, ... of the group; its threads
-  // run over the (row, four features) pairs of those rows, so that none idles when F / 4 is not
-  // a multiple of the workgroup size (the partial rows are padded to whole slices and 16-byte
-  // aligned).  The partial sums of a pair are loaded four at a time and added in item order.
+  // A workgroup takes the rows blockIdx.y, blockIdx.y + gridDim.y, ... of the group, several of
+  // them side by side; a thread owns four features (the partial rows are padded to whole slices
+  // and 16-byte aligned).  The partial sums are loaded four at a time and added in item order.
   // As planes the rows are written whole, padding features included (they are zero).
-  const int Fw = to_planes ? a.Fpad : a.F;
-  const int quads = (Fw + 3) / 4;
+  const int quads = tg_combine_quads(a.F, a.Fpad, to_planes);
+  const int rows_par = int(blockDim.x) / quads > 0 ? int(blockDim.x) / quads : 1;
   const int my_rows = (kRows - int(blockIdx.y) + int(gridDim.y) - 1) / int(gridDim.y);
   const bool scale = a.dinv_row != nullptr;
   bool bad = false;
   uint32_t tiny = 0;
-  for (int p = threadIdx.x; p < my_rows * quads; p += blockDim.x) {
-    const int rr = int(blockIdx.y) + (p / quads) * int(gridDim.y);
-    const int f4 = (p % quads) * 4;
-    const int row = a.grows[int64_t(g) * kRows + rr];
-    if (row < 0) continue;
-    const float dr = scale ? a.dinv_row[row] : 1.0f;
-    const float cr = a.corr != nullptr
-                         ? a.corr[row] * ((a.X != nullptr && a.dinv_col != nullptr) ? a.dinv_col[a.x_row_offset + row] : 1.0f)
-                         : 0.0f;
-    const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f4;
-    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-    int k = 0;
-    for (; k + 4 <= nseg; k += 4) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(pp + (k + 0) * stride);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(pp + (k + 1) * stride);
-      const f32x4 v2 = *reinterpret_cast<const f32x4*>(pp + (k + 2) * stride);
-      const f32x4 v3 = *reinterpret_cast<const f32x4*>(pp + (k + 3) * stride);
-      s += v0;
-      s += v1;
-      s += v2;
-      s += v3;
-    }
-    for (; k < nseg; ++k) s += *reinterpret_cast<const f32x4*>(pp + k * stride);
-    _Float16 hv[4], lv[4];
+  for (int q = threadIdx.x % quads; q < quads && int(threadIdx.x) < quads * rows_par; q += int(blockDim.x) >= quads ? quads : int(blockDim.x)) {
+    const int f4 = q * 4;
+    uint32_t mx[4] = {0, 0, 0, 0};
+    uint32_t nb[4];
+    float inv_in[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int f = f4 + j;
-      float y = 0.0f;
-      if (f < a.F) {
-        y = s[j];
-        if (a.addend != nullptr) y += a.addend[int64_t(row) * a.ld_addend + f];
-        if (a.corr != nullptr) {
-          float xv;
-          if (a.X != nullptr) {
-            xv = a.X[(a.x_row_offset + row) * a.ldx + f];
-          } else {
-            const char* pr = a.planes + int64_t(f / kSlice) * a.slice_bytes + (a.x_row_offset + row) * kRowBytes + (f % kSlice) * 2;
-            const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bound_of(a.state, a.Fpad)[f]));
-            xv = (float(*reinterpret_cast<const _Float16*>(pr)) + float(*reinterpret_cast<const _Float16*>(pr + kRowBytes / 2)) * (1.0f / 2048.0f)) *
-                 __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);
+      const uint32_t bnd = f < a.F ? bound_of(a.state, a.Fpad)[f] : 0u;
+      nb[j] = (to_planes && a.adapt && f < a.F) ? a.state->amax[f] : bnd;
+      const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
+      inv_in[j] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);
+    }
+    for (int r = int(threadIdx.x) / quads; r < my_rows; r += rows_par) {
+      const int rr = int(blockIdx.y) + r * int(gridDim.y);
+      const int row = a.grows[int64_t(g) * kRows + rr];
+      if (row < 0) continue;
+      const float dr = scale ? a.dinv_row[row] : 1.0f;
+      const float cr = a.corr != nullptr
+                           ? a.corr[row] * ((a.X != nullptr && a.dinv_col != nullptr) ? a.dinv_col[a.x_row_offset + row] : 1.0f)
+                           : 0.0f;
+      const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f4;
+      f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+      int k = 0;
+      for (; k + 4 <= nseg; k += 4) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(pp + (k + 0) * stride);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(pp + (k + 1) * stride);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(pp + (k + 2) * stride);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(pp + (k + 3) * stride);
+        s += v0;
+        s += v1;
+        s += v2;
+        s += v3;
+      }
+      for (; k < nseg; ++k) s += *reinterpret_cast<const f32x4*>(pp + k * stride);
+      _Float16 hv[4], lv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = f4 + j;
+        float y = 0.0f;
+        if (f < a.F) {
+          y = s[j];
+          if (a.addend != nullptr) y += a.addend[int64_t(row) * a.ld_addend + f];
+          if (a.corr != nullptr) {
+            float xv;
+            if (a.X != nullptr) {
+              xv = a.X[(a.x_row_offset + row) * a.ldx + f];
+            } else {
+              const char* pr = a.planes + int64_t(f / kSlice) * a.slice_bytes + (a.x_row_offset + row) * kRowBytes + (f % kSlice) * 2;
+              xv = (float(*reinterpret_cast<const _Float16*>(pr)) +
+                    float(*reinterpret_cast<const _Float16*>(pr + kRowBytes / 2)) * (1.0f / 2048.0f)) * inv_in[j];
+            }
+            y = fmaf(a.w_off, y, cr * xv);
+          } else if (a.w_off != 1.0f) {
+            y *= a.w_off;
           }
-          y = fmaf(a.w_off, y, cr * xv);
-        } else if (a.w_off != 1.0f) {
-          y *= a.w_off;
+          if (scale) {
+            y = y * dr;
+            if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+          }
         }
-        if (scale) {
-          y = y * dr;
-          if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+        if (to_planes) {
+          tg_split_one(y, tg_scale(nb[j]), hv[j], lv[j], tiny);
+          const uint32_t yb = __builtin_bit_cast(uint32_t, y) & 0x7FFFFFFFu;
+          mx[j] = yb > mx[j] ? yb : mx[j];
+        } else if (f < a.F) {
+          a.Y[int64_t(row) * a.ldy + f] = y;
         }
       }
       if (to_planes) {
-        const uint32_t nb = f < a.F ? (a.adapt ? a.state->amax[f] : bound_of(a.state, a.Fpad)[f]) : 0u;
-        tg_split_one(y, tg_scale(nb), hv[j], lv[j], bad, tiny);
-        const uint32_t yb = __builtin_bit_cast(uint32_t, y) & 0x7FFFFFFFu;
-        if (yb) {
-          if (f < 1024) atomicMax(&smax[f], yb);
-          else atomicMax(&a.state_out->amax[f], yb);
-        }
-      } else if (f < a.F) {
-        a.Y[int64_t(row) * a.ldy + f] = y;
+        char* dst = a.planes_out + int64_t(f4 / kSlice) * a.slice_bytes_out + (a.out_row_offset + row) * kRowBytes + (f4 % kSlice) * 2;
+        auto pack = [](_Float16 x, _Float16 y2) {
+          return uint32_t(__builtin_bit_cast(uint16_t, x)) | (uint32_t(__builtin_bit_cast(uint16_t, y2)) << 16);
+        };
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pack(hv[0], hv[1]), pack(hv[2], hv[3])};
+        *reinterpret_cast<u32x2*>(dst + kRowBytes / 2) = u32x2{pack(lv[0], lv[1]), pack(lv[2], lv[3])};
       }
     }
     if (to_planes) {
-      char* dst = a.planes_out + int64_t(f4 / kSlice) * a.slice_bytes_out + (a.out_row_offset + row) * kRowBytes + (f4 % kSlice) * 2;
-      auto pack = [](_Float16 x, _Float16 y2) {
-        return uint32_t(__builtin_bit_cast(uint16_t, x)) | (uint32_t(__builtin_bit_cast(uint16_t, y2)) << 16);
-      };
-      *reinterpret_cast<u32x2*>(dst) = u32x2{pack(hv[0], hv[1]), pack(hv[2], hv[3])};
-      *reinterpret_cast<u32x2*>(dst + kRowBytes / 2) = u32x2{pack(lv[0], lv[1]), pack(lv[2], lv[3])};
+      // the threads that share these features fold their maxima in LDS first: one atomic per
+      // feature and workgroup reaches memory (every workgroup of the launch adds to the same words)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bad |= tg_beyond(mx[j], nb[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (mx[j] && f4 + j < a.F) {
+          if (f4 + j < 4096 && rows_par > 1) atomicMax(&smax[f4 + j], mx[j]);
+          else atomicMax(&a.state_out->amax[f4 + j], mx[j]);
+        }
     }
+    if (int(blockDim.x) >= quads) break;   // one set of features per thread
   }
   if (to_planes) {
+    if (rows_par > 1) {
+      __syncthreads();
+      for (int f = threadIdx.x; f < a.F && f < 4096; f += blockDim.x)
+        if (smax[f]) atomicMax(&a.state_out->amax[f], smax[f]);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
     const bool any_bad = __any(bad);
@@ -1408,12 +1447,6 @@ __global__ __launch_bounds__(256) void k_tg_combine(TgArgs a) {
       if (tiny) atomicAdd(&a.state_out->tiny, tiny);
       if (any_bad) atomicOr(&a.state_out->flag, 1u);
     }
-    __syncthreads();
-    for (int f = threadIdx.x; f < 1024 && f < a.F; f += blockDim.x)
-      if (smax[f]) {
-        atomicMax(&a.state_out->amax[f], smax[f]);
-        atomicMax(&a.state_out->amax_all, smax[f]);
-      }
   }
 }
 
@@ -1605,7 +1638,7 @@ int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const 
   const unsigned T = unsigned(per_row >= 1024 ? 1024 : (per_row <= 256 ? 256 : (per_row + kWave - 1) / kWave * kWave));
   // every workgroup ends in one atomic per feature: few workgroups, each with many rows
   const int64_t quads = (n + 3) / 4;
-  hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(quads < 1024 ? quads : 1024)), dim3(T), 0, st, n, F, scale_row, X, ldx, s);
+  hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(quads < 512 ? quads : 512)), dim3(T), 0, st, n, F, scale_row, X, ldx, s);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
@@ -1731,7 +1764,11 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   HIP_TRY(hipGetLastError());
   sgnn::kernel_timer_end(st);
   if (long_groups > 0) {
-    hipLaunchKernelGGL(k_tg_combine, dim3(unsigned(long_groups), 64), dim3(256), 0, st, a);
+    const int quads = tg_combine_quads(a.F, a.Fpad, planes_out != nullptr);
+    // 64 workgroups per split group where there are few groups, fewer where there are thousands
+    // (every workgroup ends in one atomic per feature when it writes planes)
+    const unsigned gy = unsigned(long_groups >= 4096 ? 1 : (4096 / long_groups > 64 ? 64 : 4096 / long_groups));
+    hipLaunchKernelGGL(k_tg_combine, dim3(unsigned(long_groups), gy), dim3(tg_combine_threads(quads)), 0, st, a);
     HIP_TRY(hipGetLastError());
   }
   if (rowptr != nullptr) {
