@@ -395,6 +395,17 @@ int sgnn_spmm_rowgroup_f32(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t 
 int sgnn_row_scale_f32(int64_t n, int64_t F, const float* scale,
                        const float* in, int64_t ldin, float* out, int64_t ldout, void* stream);
 
+/*
+ * out[i, :] = ((a[i, :] + b[i, :]) * scale[i]) (* scale[i] again when twice != 0).
+ * The row-partitioned path multiplies a rank's own-columns block while the other ranks' rows
+ * of X travel and its remote-columns block when they have landed; this adds the two blocks'
+ * raw sums in that fixed order and applies the row scaling of utils.py:95 (twice: followed by
+ * utils.py:93 of the next hop).  No counterpart in the reference, whose ranks are replicas
+ * (main.py:39-41).
+ */
+int sgnn_add_scale_f32(int64_t n, int64_t F, const float* a, int64_t lda, const float* b, int64_t ldb,
+                       const float* scale, int twice, float* out, int64_t ldout, void* stream);
+
 /* sampling flags */
 #define SGNN_SAMPLE_SKIP_SELF  1   /* write 0 where idx[i] == idx[j]: sample the matrix without its diagonal */
 

@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -348,6 +349,26 @@ __global__ __launch_bounds__(256) void k_row_scale(int64_t n, int64_t F, const f
   for (int64_t f = threadIdx.x & (kWave - 1); f < F; f += kWave) dst[f] = src[f] * s;
 }
 
+// out[r, :] = ((a[r, :] + b[r, :]) * scale[r]) (* scale[r]): the raw sums of a row block's two
+// column blocks (own columns, remote columns) added in that fixed order, then the row scaling of
+// utils.py:95 (and, between hops, utils.py:93 of the next hop)
+__global__ __launch_bounds__(256) void k_add_scale(int64_t n, int64_t F, const float* __restrict__ a, int64_t lda,
+                                                   const float* __restrict__ b, int64_t ldb,
+                                                   const float* __restrict__ scale, int twice,
+                                                   float* __restrict__ out, int64_t ldout) {
+  const int64_t r = blockIdx.x * int64_t(4) + threadIdx.x / kWave;
+  if (r >= n) return;
+  const float s = scale[r];
+  const float* pa = a + r * lda;
+  const float* pb = b + r * ldb;
+  float* dst = out + r * ldout;
+  for (int64_t f = threadIdx.x & (kWave - 1); f < F; f += kWave) {
+    float y = (pa[f] + pb[f]) * s;
+    if (twice) y = y * s;
+    dst[f] = y;
+  }
+}
+
 struct SpmmWs {
   int32_t *counters, *seg_row, *seg_k, *long_row, *long_slot;
   float* partial;
@@ -507,8 +528,13 @@ int fail(int code, const std::string& msg) {
 }
 
 namespace {
-struct TimerPair { hipEvent_t e0, e1; };
+// Kernel timer.  One pool of event pairs for the process, guarded by a mutex (entry points may
+// be called from several host threads); a pair belongs to the device it was created on and is
+// created anew when its slot is reused from another device.  A pair left open by a launch path
+// that returned early is abandoned by the next begin.
+struct TimerPair { hipEvent_t e0, e1; int dev; };
 constexpr size_t kMaxTimed = 8192;      // launches kept between two reads; later ones go untimed
+std::mutex g_timer_mu;
 bool g_timer_on = false;
 std::vector<TimerPair> g_timer_pool;    // events are created on first use and kept
 size_t g_timer_used = 0;
@@ -516,9 +542,21 @@ bool g_timer_open = false;
 }  // namespace
 
 void kernel_timer_begin(hipStream_t st) {
-  if (!g_timer_on || g_timer_open || g_timer_used >= kMaxTimed) return;
+  std::lock_guard<std::mutex> lock(g_timer_mu);
+  g_timer_open = false;
+  if (!g_timer_on || g_timer_used >= kMaxTimed) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  if (g_timer_used < g_timer_pool.size() && g_timer_pool[g_timer_used].dev != dev) {
+    for (size_t i = g_timer_used; i < g_timer_pool.size(); ++i) {   // this pair and the ones behind it are recreated as they come up
+      (void)hipEventDestroy(g_timer_pool[i].e0);
+      (void)hipEventDestroy(g_timer_pool[i].e1);
+    }
+    g_timer_pool.resize(g_timer_used);
+  }
   if (g_timer_used == g_timer_pool.size()) {
     TimerPair p;
+    p.dev = dev;
     if (hipEventCreate(&p.e0) != hipSuccess) return;
     if (hipEventCreate(&p.e1) != hipSuccess) { (void)hipEventDestroy(p.e0); return; }
     g_timer_pool.push_back(p);
@@ -527,6 +565,7 @@ void kernel_timer_begin(hipStream_t st) {
 }
 
 void kernel_timer_end(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_timer_mu);
   if (!g_timer_open) return;
   g_timer_open = false;
   if (hipEventRecord(g_timer_pool[g_timer_used].e1, st) == hipSuccess) ++g_timer_used;
@@ -547,7 +586,12 @@ int sgnn_tune_set(const char* key, int value) {
   else if (!std::strcmp(key, "tg_seg")) sgnn::set_tilegroup_segment(value);
   else if (!std::strcmp(key, "tg_mode")) sgnn::set_tilegroup_mode(value);
   else if (!std::strcmp(key, "tg_order")) sgnn::set_tilegroup_order(value);
-  else if (!std::strcmp(key, "time_kernel")) { sgnn::g_timer_on = value != 0; sgnn::g_timer_used = 0; }
+  else if (!std::strcmp(key, "time_kernel")) {
+    std::lock_guard<std::mutex> lock(sgnn::g_timer_mu);
+    sgnn::g_timer_on = value != 0;
+    sgnn::g_timer_used = 0;
+    sgnn::g_timer_open = false;
+  }
   else return fail(SGNN_ERR_INVALID, std::string("unknown tuning key ") + key);
   return SGNN_OK;
 }
@@ -557,6 +601,7 @@ const char* sgnn_last_error(void) { return sgnn::g_err.c_str(); }
 int sgnn_kernel_time_ms(double* total_ms, int64_t* launches) {
   if (!total_ms || !launches) return fail(SGNN_ERR_INVALID, "null pointer");
   double sum = 0;
+  std::lock_guard<std::mutex> lock(sgnn::g_timer_mu);
   for (size_t i = 0; i < sgnn::g_timer_used; ++i) {
     float ms = 0;
     HIP_TRY(hipEventSynchronize(sgnn::g_timer_pool[i].e1));
@@ -638,6 +683,18 @@ int sgnn_row_scale_f32(int64_t n, int64_t F, const float* scale, const float* in
   if (!scale || !in || !out) return fail(SGNN_ERR_INVALID, "null pointer");
   hipLaunchKernelGGL(k_row_scale, dim3(unsigned((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      n, F, scale, in, ldin, out, ldout);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+int sgnn_add_scale_f32(int64_t n, int64_t F, const float* a, int64_t lda, const float* b, int64_t ldb,
+                       const float* scale, int twice, float* out, int64_t ldout, void* stream) {
+  if (n < 0 || F < 0) return fail(SGNN_ERR_INVALID, "negative size");
+  if (n == 0 || F == 0) return SGNN_OK;
+  if (!a || !b || !scale || !out) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (lda < F || ldb < F || ldout < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
+  hipLaunchKernelGGL(k_add_scale, dim3(unsigned((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n, F, a, lda, b, ldb, scale, twice, out, ldout);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }

@@ -78,9 +78,9 @@ static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wa
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
 static_assert(kTableBytes + kWaves * kStageOutBytes <= kLdsBytes, "the write-out staging must fit the ring");
 
-int g_seg_stages = 0;     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
-int g_order_cols = 0;     // > 0: work items ordered by column blocks of this width; 0: longest first (sgnn_tune_set("tg_order", v))
-int g_tg_mode = 0;         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only; results are then wrong
+std::atomic<int> g_seg_stages{0};     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
+std::atomic<int> g_order_cols{0};     // > 0: work items ordered by column blocks of this width; 0: longest first (sgnn_tune_set("tg_order", v))
+std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only; results are then wrong
 
 struct TgState {          // device words that carry an operand's scales and its fall-back flag to the SpMM that reads it
   uint32_t amax_all;      // bit pattern of the largest |element| over all features (diagnostics)
@@ -1604,7 +1604,7 @@ int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t sta
                      w.lidx, w.itmp, w.cap_items, p.long_group, p.long_slot, p.long_nseg);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_tg_item_keys, blocks_for(items), dim3(T), 0, st, items, w.itmp, w.cap_items, p.stage_col,
-                     g_order_cols, w.ikey_a);
+                     int(g_order_cols.load()), w.ikey_a);
   HIP_TRY(hipGetLastError());
   size_t pb = w.prim_bytes;
   HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.ikey_a, w.ikey_b, size_t(items), 0u, 64u, st));

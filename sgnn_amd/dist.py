@@ -18,6 +18,19 @@ equal-piece all-gather moves 2.6 times the rows there are.)  One hop is
   3. SpMM of the local row block against the gathered buffer  (utils.py:94)
   4. scale the local output rows by the local ``dinv``        (utils.py:95, fused)
 
+The local rows' CSR is also kept cut in two by column ownership -- the block over the rank's
+own columns and the block over everyone else's -- and the default schedule
+(``overlap="local-block"``) multiplies the own-columns block, which needs nothing from the
+other ranks, on the compute stream while the exchange runs on a second stream; the
+remote-columns block follows when the rows have landed and the two raw sums are added in that
+fixed order before the row scaling (deterministic; ``overlap="none"`` keeps the one-block
+schedule, whose rows are reduced exactly as on one GPU).  Where the remote-columns block is
+large and shared enough for the tile-group (matrix-core) kernel, what travels is not fp32
+rows but the operand's fp16 planes (the same four bytes per element), one all-gather per
+128-feature slice: a rank splits only its own rows, after the ranks have agreed on the
+per-feature maxima with one small all-reduce, and on later hops the epilogue writes the
+rank's rows of the next operand straight into its piece of the next gather buffer.
+
 Blocks are padded to a common row count so that the exchange is ONE
 ``all_gather_into_tensor`` of equal pieces; node ids are remapped once into the
 padded index space (owner * max_rows + position in the owner's block), in which
@@ -48,9 +61,15 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .norm_adj import TILEGROUP_MIN_NNZ, NormAdj, tilegroup_build, tilegroup_hop
+from .norm_adj import TILEGROUP_MIN_NNZ, NormAdj, _keep, tilegroup_build, tilegroup_buffers, tilegroup_hop
 
 TILEGROUP_MIN_ENTRIES_PER_OPERAND_ROW = 40
+
+
+def ctypes_ptr(t, byte_offset=0):
+    """Device pointer ``byte_offset`` bytes into a tensor."""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + int(byte_offset))
 
 
 def grid_layout(rank, world, feature_groups, F, align=2):
@@ -148,8 +167,18 @@ class PartitionedAdj:
     caller hands ``X[rows]`` to ``propagate`` and gets ``Y[rows]`` back."""
 
     def __init__(self, local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group=None,
-                 splits=None, halo=None):
+                 splits=None, halo=None, own=None, remote=None):
         self.local = local                      # block over (rows_local x padded columns)
+        # the same rows cut by column ownership (None: one-block schedule only)
+        self.own, self.remote = own, remote
+        self.overlap = "local-block" if own is not None else "none"
+        # exchange fp16 planes and multiply on the matrix cores: None = where the remote-columns
+        # block merits the tile-group kernel (all ranks agree), True / False force it
+        self.use_planes = None
+        self._planes_decision = None
+        self._plane_bufs = {}
+        self._raw = {}
+        self.last_schedule = None               # what the last propagate call ran (diagnostics, bench line)
         self.rows, self.rank, self.world, self.n = rows, rank, world, n
         self.n_local = int(rows.numel())
         self.max_rows = int(max_rows)
@@ -167,7 +196,7 @@ class PartitionedAdj:
     # ------------------------------------------------------------------ build
     @classmethod
     def from_coo(cls, row, col, val, n, device, rank, world, group=None, local_factory=None,
-                 partition="degree_cyclic", exchange="allgather"):
+                 partition="degree_cyclic", exchange="allgather", overlap="local-block"):
         """Every rank passes the same COO (entries of other ranks' rows are dropped
         here).  ``local_factory`` is a test hook that builds the local block from
         ``(row_padded, col_padded, val, n_rows, n_padded, first_padded_row)``; the
@@ -246,7 +275,12 @@ class PartitionedAdj:
             local = _LocalBlock.build(lrow, lcol, lval, n_pad, r0, r0 + int(rows.numel()), device)
         if halo is not None:
             halo["send_idx"] = halo["send_idx"].to(device)
-        return cls(local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group, splits, halo)
+        if overlap not in ("local-block", "none"):
+            raise ValueError(f"unknown overlap {overlap!r}")
+        own = remote = None
+        if overlap == "local-block" and world > 1 and hasattr(local, "split_columns"):
+            own, remote = local.split_columns(r0, r0 + max_rows)
+        return cls(local, rows, max_rows, rank, world, n, global_nnz, global_max_degree, group, splits, halo, own, remote)
 
     # ------------------------------------------------------------------ apply
     def _buffers(self, F, device, dtype):
@@ -256,7 +290,7 @@ class PartitionedAdj:
             rows = self.max_rows * self.world if self.halo is None else self.max_rows + self.halo["n_recv"]
             Fp = (F + 3) // 4 * 4      # rows on 16-byte boundaries for the row-group kernel's loads
             b = [torch.zeros((rows, Fp), dtype=dtype, device=device) for _ in range(2)]
-            self._gather = {key: b}
+            _keep(self._gather, key, b)      # a stack of layers alternates between a few widths
         return b
 
     def _all_gather(self, full, piece, force=False):
@@ -267,7 +301,10 @@ class PartitionedAdj:
             # one GPU in tests; production runs use the nccl backend = RCCL)
             host = torch.empty(full.shape, dtype=full.dtype)
             dist.all_gather_into_tensor(host.view(-1), piece.cpu().reshape(-1), group=self.group)
-            full.copy_(host)
+            # (the rank's own piece is already in place and may be being read by the own-columns multiply)
+            lo, hi = self.rank * self.max_rows, (self.rank + 1) * self.max_rows
+            full[:lo].copy_(host[:lo])
+            full[hi:].copy_(host[hi:])
             return
         # on the GPU the piece is sent in place (it already sits in its slot of `full`)
         inp = piece if piece.is_cuda else piece.clone()
@@ -286,9 +323,10 @@ class PartitionedAdj:
             return
         dist.all_to_all_single(recv, send, h["recv_counts"], h["send_counts"], group=self.group)
 
-    def propagate(self, X_local, order=1, slices=1):
+    def propagate(self, X_local, order=1, slices=1, overlap=None):
         """``A_hat^order . X`` for the local rows; X_local = this rank's rows of X.
-        Returns this rank's rows of the result."""
+        Returns this rank's rows of the result.  ``overlap``: None = the schedule the handle
+        was built for ("local-block" unless built with ``overlap="none"``)."""
         order = int(order)
         if order <= 0:
             return X_local
@@ -296,8 +334,23 @@ class PartitionedAdj:
         if X_local.shape[0] != rows:
             raise ValueError(f"rank {self.rank} owns {rows} rows, got {X_local.shape[0]}")
         F = X_local.shape[1]
+        mode = self.overlap if overlap is None else overlap
+        if mode not in ("local-block", "none"):
+            raise ValueError(f"unknown overlap {mode!r}")
+        if self.own is None or self.world == 1:
+            mode = "none"
         if slices > 1 and X_local.is_cuda and self.halo is None:
+            self.last_schedule = "sliced"
             return self._propagate_sliced(X_local, order, slices)
+        if mode == "local-block":
+            if self._planes_ok(X_local):
+                out = self._propagate_planes(X_local, order)
+                if out is not None:
+                    self.last_schedule = "local-block, fp16 planes exchanged"
+                    return out
+            self.last_schedule = "local-block"
+            return self._propagate_split(X_local, order)
+        self.last_schedule = "none"
         bufs = self._buffers(F, X_local.device, X_local.dtype)
         lo = self.rank * self.max_rows if self.halo is None else 0
         src = X_local
@@ -319,6 +372,187 @@ class PartitionedAdj:
             else:
                 nxt = bufs[(h + 1) % 2][lo:lo + rows, :F]
                 self.local.spmm_into(full[:, :F], nxt, final=False)     # epilogue: (s*d)*d
+        return out
+
+    # ---------------------------------------------------------- local-block overlap
+    def _streams(self, device):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        return torch.cuda.current_stream(device), self._comm_stream
+
+    def _propagate_split(self, X_local, order):
+        """Exchange of fp32 rows overlapped with the own-columns multiply: the own-columns block
+        reads only the rank's own (already scaled) rows, so it starts at once on the compute
+        stream while the exchange runs on the other; the remote-columns block follows when the
+        rows have landed; the raw sums of the two are added in that order and row-scaled."""
+        rows, F = self.n_local, X_local.shape[1]
+        dev = X_local.device
+        bufs = self._buffers(F, dev, X_local.dtype)
+        key = (F, dev, X_local.dtype)
+        raw = self._raw.get(key)
+        if raw is None:
+            raw = _keep(self._raw, key, [torch.empty((rows, F), dtype=X_local.dtype, device=dev) for _ in range(2)])
+        s1, s2 = raw
+        lo = self.rank * self.max_rows if self.halo is None else 0
+        cuda = X_local.is_cuda
+        main, comm = self._streams(dev) if cuda else (None, None)
+        out = None
+        for h in range(order):
+            full = bufs[h % 2]
+            piece = full[lo:lo + self.max_rows]
+            if h == 0:
+                self.local.scale_rows_into(X_local, piece[:rows, :F])       # utils.py:93
+            if cuda:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ready)
+                    self._all_gather(full, piece) if self.halo is None else self._exchange_referenced(full)
+                    done = torch.cuda.Event()
+                    done.record(comm)
+                self.own.spmm_raw_into(full[:, :F], s1)          # while the other ranks' rows travel
+                main.wait_event(done)
+            else:
+                self._all_gather(full, piece) if self.halo is None else self._exchange_referenced(full)
+                self.own.spmm_raw_into(full[:, :F], s1)
+            self.remote.spmm_raw_into(full[:, :F], s2)
+            last = h == order - 1
+            if last:
+                out = torch.empty((rows, F), dtype=X_local.dtype, device=dev)
+                self.local.finish_into(s1, s2, out, final=True)
+            else:
+                self.local.finish_into(s1, s2, bufs[(h + 1) % 2][lo:lo + rows, :F], final=False)
+        return out
+
+    def _agree(self, value, device, op):
+        """One integer agreed on by the ranks of the exchange (collective)."""
+        if self.world == 1 or not dist.is_initialized():
+            return int(value)
+        host = dist.get_backend(self.group) == "gloo"
+        t = torch.tensor([int(value)], dtype=torch.int32, device="cpu" if host else device)
+        dist.all_reduce(t, op=op, group=self.group)
+        return int(t.item())
+
+    def _planes_ok(self, X_local):
+        """Whether this propagation exchanges fp16 planes and multiplies on the matrix cores: the
+        remote-columns block must merit the tile-group kernel (uniform weights, at least 4 M
+        stored entries, rows that share enough columns: the tests of NormAdj._tilegroup_plan, on
+        what is by far the larger of the rank's two blocks) on every rank."""
+        if not X_local.is_cuda or X_local.dtype != torch.float32 or self.use_planes is False:
+            return False
+        if self.own is None or not hasattr(self.own, "tilegroup_plan") or X_local.shape[1] < 16:
+            return False
+        if self._planes_decision is None:
+            force = self.use_planes is True
+            ok = self.remote.adj.w_off is not None and self.remote.adj.nnz > 0
+            if ok and not force:
+                ok = self.remote.adj.nnz >= TILEGROUP_MIN_NNZ
+            if ok:
+                ok = self.remote.tilegroup_plan(auto=not force) is not None
+            ok = bool(self._agree(1 if ok else 0, X_local.device, dist.ReduceOp.MIN))
+            if ok:
+                ok = self.own.tilegroup_plan(auto=False) is not None
+            self._planes_decision = ok
+        return self._planes_decision
+
+    def _planes_buffers(self, F, order, device):
+        lib = _lib.load()
+        b = self._plane_bufs.get(F)
+        n_cols = self.local.n_cols
+        S = (F + 127) // 128
+        if b is None:
+            nbytes = lib.sgnn_tilegroup_planes_bytes(n_cols, F)
+            sb = lib.sgnn_tilegroup_state_bytes(F)
+            b = dict(flat=[torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(2)], nbytes=nbytes,
+                     sb=sb, states=torch.zeros((1, sb // 4), dtype=torch.int32, device=device),
+                     s1=torch.empty((self.n_local, F), dtype=torch.float32, device=device),
+                     ws_own=torch.empty(max(lib.sgnn_spmm_tilegroup_workspace_bytes(self.own._tg["slots"], F), 256),
+                                        dtype=torch.uint8, device=device),
+                     ws_rem=torch.empty(max(lib.sgnn_spmm_tilegroup_workspace_bytes(self.remote._tg["slots"], F), 256),
+                                        dtype=torch.uint8, device=device))
+            b["G"] = [f[:S * n_cols * 512].view(S, n_cols, 512) for f in b["flat"]]
+            _keep(self._plane_bufs, F, b)
+        if b["states"].shape[0] < order:
+            b["states"] = torch.zeros((order, b["sb"] // 4), dtype=torch.int32, device=device)
+        return b
+
+    def _exchange_planes(self, G):
+        """One exchange per 128-feature slice: a slice of the operand is [padded nodes, 512 bytes]
+        and the rank's piece of it is contiguous."""
+        lo = self.rank * self.max_rows if self.halo is None else 0
+        for s in range(G.shape[0]):
+            full = G[s]
+            if self.halo is None:
+                self._all_gather(full, full[lo:lo + self.max_rows])
+            else:
+                self._exchange_referenced(full)
+
+    def _propagate_planes(self, X_local, order):
+        """Local-block overlap with the operand exchanged as fp16 planes (see the module text).
+        Returns None when some rank's operand could not go through the planes (non-finite
+        values, a dynamic range fp16 pairs cannot hold): the caller then runs the fp32 schedule."""
+        lib = _lib.load()
+        rows, F = self.n_local, X_local.shape[1]
+        dev = X_local.device
+        X_local = X_local if X_local.stride(1) == 1 else X_local.contiguous()
+        b = self._planes_buffers(F, order, dev)
+        n_cols = self.local.n_cols
+        lo = self.rank * self.max_rows if self.halo is None else 0
+        Fpad = (F + 127) // 128 * 128
+        st = _lib.current_stream(dev)
+        main, comm = self._streams(dev)
+        states = b["states"]
+        own, rem = self.own, self.remote
+        dinv = self.local.dinv
+        # operand 0: per-feature maxima of the local rows, agreed on by all ranks, then the local split
+        _lib.check(lib.sgnn_tilegroup_amax_f32(rows, F, _lib.ptr(dinv), _lib.ptr(X_local), X_local.stride(0),
+                                               _lib.ptr(states[0]), st))
+        amax = states[0, 8:8 + Fpad]
+        if dist.get_backend(self.group) == "gloo":
+            host = amax.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            amax.copy_(host)
+        else:
+            dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)
+        piece0 = b["G"][0][:, lo:lo + self.max_rows]
+        _lib.check(lib.sgnn_tilegroup_planes_f32(rows, F, _lib.ptr(dinv), _lib.ptr(X_local), X_local.stride(0),
+                                                 ctypes_ptr(b["flat"][0], lo * 512), n_cols, rows, _lib.ptr(states[0]), st))
+        del piece0
+        out = torch.empty((rows, F), dtype=torch.float32, device=dev)
+        for h in range(order):
+            G, flat, state = b["G"][h % 2], b["flat"][h % 2], states[h]
+            last = h == order - 1
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                self._exchange_planes(G)
+                done = torch.cuda.Event()
+                done.record(comm)
+            # own-columns block: raw pattern sums into s1, from the rank's own rows of the planes
+            po = own._tg
+            _lib.check(lib.sgnn_spmm_tilegroup_f32(
+                rows, n_cols, F, _lib.ptr(po["buf"]), po["bytes"], po["stages"], po["steps"], po["items"], po["slots"],
+                po["n_long"], None, 1.0, None, _lib.ptr(flat), b["nbytes"], _lib.ptr(state), _lib.ptr(b["s1"]), F,
+                _lib.EPI_SCALE_ROW, _lib.ptr(b["ws_own"]), b["ws_own"].numel(), own.adj.nnz, None, None, None, None, None, 0,
+                None, 0, 0, None, 0, None, 0, 0, None, 0, st))
+            main.wait_event(done)
+            # remote-columns block: + s1, weights, diagonal correction, row scaling; the last hop
+            # writes fp32, the others the rank's rows of the next operand's planes
+            pr = rem._tg
+            nxt = b["flat"][(h + 1) % 2]
+            _lib.check(lib.sgnn_spmm_tilegroup_f32(
+                rows, n_cols, F, _lib.ptr(pr["buf"]), pr["bytes"], pr["stages"], pr["steps"], pr["items"], pr["slots"],
+                pr["n_long"], _lib.ptr(dinv), float(own.adj.w_off), _lib.ptr(own.adj.corr), _lib.ptr(flat), b["nbytes"],
+                _lib.ptr(state), _lib.ptr(out) if last else None, F,
+                _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2, _lib.ptr(b["ws_rem"]), b["ws_rem"].numel(),
+                rem.adj.nnz, None, None, None, None, None, 0, None, 0, lo, _lib.ptr(b["s1"]), F,
+                None if last else _lib.ptr(nxt), n_cols, lo, None if last else _lib.ptr(states[h + 1]), 0, st))
+        # one agreement per call: did every rank's every operand go through the planes?
+        head = states[:order, :8].cpu()           # synchronises
+        refused = bool((head[:, 1] != 0).any() or (head[:, 4] > head[:, 6]).any())
+        if self._agree(1 if refused else 0, dev, dist.ReduceOp.MAX):
+            return None
         return out
 
     def _propagate_sliced(self, X_local, order, slices):
@@ -343,7 +577,7 @@ class PartitionedAdj:
         if fulls is None:
             fulls = [torch.zeros((self.max_rows * self.world, (bounds[s + 1] - bounds[s] + 3) // 4 * 4),
                                  dtype=X_local.dtype, device=dev) for s in range(len(bounds) - 1)]
-            self._slice_bufs = {key: fulls}
+            _keep(self._slice_bufs, key, fulls)
         for h in range(order):
             last = h == order - 1
             out = torch.empty((rows, F), dtype=X_local.dtype, device=dev)
@@ -386,6 +620,7 @@ class _LocalBlock:
         # tile-group (matrix-core) kernel on the rank's rows: None = where it pays (the same test
         # as NormAdj applies), True / False force it on / off
         self.use_tilegroup = None
+        self.use_rowgroup = True        # False: the plain CSR kernel (whose rows are reduced exactly as on one GPU)
         self._tg = None
 
     @classmethod
@@ -462,14 +697,59 @@ class _LocalBlock:
             self._tg = tilegroup_build(self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a.device, auto)
         return self._tg or None
 
+    def split_columns(self, c0, c1):
+        """The same rows cut in two by column: the block over columns [c0, c1) -- the rank's own
+        rows of the operand -- and the block over all other columns.  Both keep the padded column
+        space, the rows' ``dinv`` and the uniform off-diagonal weight; the diagonal (and with it
+        the diagonal correction of a weight-2 graph) belongs to the own-columns block."""
+        a = self.adj
+        dev = a.device
+        counts = (a.rowptr[1:] - a.rowptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(self.n_rows, device=dev), counts)
+        inside = (a.colidx >= c0) & (a.colidx < c1)
+        parts = []
+        for keep, corr in ((inside, a.corr), (~inside, None)):
+            cnt = torch.bincount(rows[keep], minlength=self.n_rows)
+            rowptr = torch.zeros(self.n_rows + 1, dtype=torch.int32, device=dev)
+            rowptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+            colidx = a.colidx[keep].contiguous()
+            vals = None if a.unit_weights else a.vals[keep].contiguous()
+            block = NormAdj(self.n_rows, rowptr, colidx, vals, a.deg, a.dinv, unit_weights=a.unit_weights,
+                            w_off=a.w_off, corr=corr)
+            parts.append(_LocalBlock(block, self.dinv, self.n_rows, self.n_cols, self.x_row_offset))
+        return parts[0], parts[1]
+
+    def tilegroup_plan(self, auto):
+        """Tile-group plan of this block's pattern (kept); None when ``auto`` and its rows share too
+        few columns, or when its weights differ."""
+        a = self.adj
+        if a.nnz == 0 or a.w_off is None:
+            return None
+        if self._tg is None or (self._tg is False and not auto):
+            self._tg = tilegroup_build(self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a.device, auto)
+        return self._tg or None
+
     def spmm_into(self, full, out, final):
         """out[rows_local, F] = dinv . (block . full), or (dinv . s) . dinv when not final."""
+        self._multiply(full, out, self.dinv, _lib.EPI_SCALE_ROW if final else _lib.EPI_SCALE_ROW2, True)
+
+    def spmm_raw_into(self, full, out):
+        """out[rows_local, F] = block . full with the block's weights and no row scaling: the raw
+        sums of one column block, for ``finish_into``."""
+        self._multiply(full, out, None, _lib.EPI_SCALE_ROW, False)
+
+    def finish_into(self, s1, s2, out, final):
+        """out = dinv . (s1 + s2), or that times dinv again when not final (sgnn_add_scale_f32)."""
+        _lib.check(_lib.load().sgnn_add_scale_f32(self.n_rows, s1.shape[1], _lib.ptr(s1), s1.stride(0), _lib.ptr(s2),
+                                                  s2.stride(0), _lib.ptr(self.dinv), 0 if final else 1, _lib.ptr(out),
+                                                  out.stride(0), _lib.current_stream(s1.device)))
+
+    def _multiply(self, full, out, dinv_row, epi, allow_tilegroup):
         lib = _lib.load()
         a = self.adj
         F = full.shape[1]
         dev = full.device
-        epi = _lib.EPI_SCALE_ROW if final else _lib.EPI_SCALE_ROW2
-        tg = self._tilegroup_plan(F)
+        tg = self._tilegroup_plan(F) if allow_tilegroup else None
         if tg is not None:
             # the gathered rows arrive scaled (utils.py:93 was applied before the exchange): split as they are
             nbytes = lib.sgnn_spmm_workspace_bytes(self.n_rows, a.nnz, F)
@@ -478,10 +758,10 @@ class _LocalBlock:
                 ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
                 self._ws[("csr", F)] = ws
             tilegroup_hop(tg, self.n_rows, self.n_cols, a.nnz, a.rowptr, a.colidx, a._vals, F, full, full.stride(0),
-                          out, out.stride(0), self.dinv, None, a.w_off, None, epi, ws, dev)
+                          out, out.stride(0), dinv_row, None, a.w_off, None, epi, ws, dev)
             return
         aligned = full.data_ptr() % 16 == 0 and full.stride(0) % 4 == 0      # 16-byte row loads
-        plan = self._plan(F) if aligned else None
+        plan = self._plan(F) if aligned and self.use_rowgroup else None
         if plan is not None:
             nbytes = lib.sgnn_spmm_rowgroup_workspace_bytes(plan["slots"], plan["R"], F)
             ws = self._ws.get(("rg", F))
@@ -490,7 +770,7 @@ class _LocalBlock:
                 self._ws[("rg", F)] = ws
             _lib.check(lib.sgnn_spmm_rowgroup_f32(
                 self.n_rows, self.n_cols, a.nnz, F, plan["R"], _lib.ptr(plan["buf"]), plan["bytes"],
-                _lib.ptr(plan["gw"]), plan["items"], plan["slots"], plan["n_long"], _lib.ptr(self.dinv), None,
+                _lib.ptr(plan["gw"]), plan["items"], plan["slots"], plan["n_long"], _lib.ptr(dinv_row), None,
                 float(a.w_off if a.w_off is not None else 1.0), _lib.ptr(a.corr), self.x_row_offset,
                 _lib.ptr(full), full.stride(0), _lib.ptr(out), out.stride(0), epi, _lib.ptr(ws), ws.numel(),
                 _lib.current_stream(dev)))
@@ -502,6 +782,6 @@ class _LocalBlock:
             self._ws[("csr", F)] = ws
         _lib.check(lib.sgnn_spmm_csr_f32(
             self.n_rows, self.n_cols, a.nnz, F, _lib.ptr(a.rowptr), _lib.ptr(a.colidx),
-            None if a.unit_weights else _lib.ptr(a.vals), _lib.ptr(self.dinv), None,
+            None if a.unit_weights else _lib.ptr(a.vals), _lib.ptr(dinv_row), None,
             _lib.ptr(full), full.stride(0), _lib.ptr(out), out.stride(0), epi, _lib.ptr(ws), ws.numel(),
             _lib.current_stream(dev)))

@@ -41,6 +41,29 @@ class OracleBlock:
     def scale_rows_into(self, src, dst):
         dst.copy_(src * torch.from_numpy(self.dinv)[:, None])
 
+    def split_columns(self, c0, c1):
+        """The block over columns [c0, c1) and the block over all others (same rows, same dinv)."""
+        import copy
+        rows = np.repeat(np.arange(self.n_rows), np.diff(self.rowptr))
+        inside = (self.colidx >= c0) & (self.colidx < c1)
+        parts = []
+        for keep in (inside, ~inside):
+            b = copy.copy(self)
+            b.rowptr = np.concatenate(([0], np.cumsum(np.bincount(rows[keep], minlength=self.n_rows)))).astype(np.int32)
+            b.colidx, b.vals = self.colidx[keep], self.vals[keep]
+            parts.append(b)
+        return parts[0], parts[1]
+
+    def spmm_raw_into(self, full, out):
+        import scipy.sparse as sp
+        A = sp.csr_matrix((self.vals.astype(np.float64), self.colidx, self.rowptr), shape=(self.n_rows, self.n_cols))
+        out.copy_(torch.from_numpy((A @ full.numpy().astype(np.float64)).astype(np.float32)))
+
+    def finish_into(self, s1, s2, out, final):
+        d = torch.from_numpy(self.dinv)[:, None]
+        y = (s1 + s2) * d
+        out.copy_(y if final else y * d)
+
     def spmm_into(self, full, out, final):
         import scipy.sparse as sp
         A = sp.csr_matrix((self.vals.astype(np.float64), self.colidx, self.rowptr), shape=(self.n_rows, self.n_cols))
@@ -51,14 +74,16 @@ class OracleBlock:
         out.copy_(torch.from_numpy(y.astype(np.float32)))
 
 
-def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic", exchange="allgather"):
+def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic", exchange="allgather",
+            overlap="local-block"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sgnn_amd.dist import PartitionedAdj
         padj = PartitionedAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), None, n, "cpu", rank, world,
-                                       local_factory=OracleBlock, partition=partition, exchange=exchange)
+                                       local_factory=OracleBlock, partition=partition, exchange=exchange, overlap=overlap)
+        assert padj.overlap == (overlap if world > 1 else "none")
         rows = padj.rows.numpy()
         if exchange == "referenced":
             assert padj.halo is not None and sum(padj.halo["recv_counts"]) == padj.halo["n_recv"]
@@ -66,18 +91,24 @@ def _worker(rank, world, port, n, r, c, X, order, q, partition="degree_cyclic", 
             assert np.array_equal(rows, np.arange(padj.row_begin, padj.row_end))
         Xl = torch.from_numpy(X[rows].copy())
         Y = padj.propagate(Xl, order)
+        if overlap == "local-block" and world > 1:
+            # the one-block schedule on the same handle: same rows, to rounding of the two-block sum
+            Y1 = padj.propagate(Xl, order, overlap="none")
+            assert float((Y - Y1).norm() / Y1.norm()) <= 1e-6
         q.put((rank, rows, Y.numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,order,partition,exchange", [
-    (2, 1, "degree_cyclic", "allgather"), (2, 2, "degree_cyclic", "allgather"), (3, 3, "degree_cyclic", "allgather"),
-    (3, 2, "contiguous", "allgather"), (8, 2, "degree_cyclic", "allgather"),
-    (2, 2, "degree_cyclic", "referenced"), (4, 3, "degree_cyclic", "referenced"), (3, 2, "contiguous", "referenced"),
-    (8, 2, "degree_cyclic", "auto")])
-def test_row_partitioned_matches_single(world, order, partition, exchange):
+@pytest.mark.parametrize("world,order,partition,exchange,overlap", [
+    (2, 1, "degree_cyclic", "allgather", "local-block"), (2, 2, "degree_cyclic", "allgather", "none"),
+    (3, 3, "degree_cyclic", "allgather", "local-block"),
+    (3, 2, "contiguous", "allgather", "local-block"), (8, 2, "degree_cyclic", "allgather", "local-block"),
+    (2, 2, "degree_cyclic", "referenced", "local-block"), (4, 3, "degree_cyclic", "referenced", "none"),
+    (3, 2, "contiguous", "referenced", "local-block"),
+    (8, 2, "degree_cyclic", "auto", "local-block")])
+def test_row_partitioned_matches_single(world, order, partition, exchange, overlap):
     from sgnn_amd.graphgen import symmetric_simple_numpy
     n, F = 700, 12
     r, c = symmetric_simple_numpy(n, 4000, seed=3)
@@ -87,7 +118,7 @@ def test_row_partitioned_matches_single(world, order, partition, exchange):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, q, partition, exchange))
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, r, c, X, order, q, partition, exchange, overlap))
              for k in range(world)]
     for p in procs:
         p.start()
