@@ -54,8 +54,10 @@ def kernel_of(adj, F):
     """(label, kernels of one hop) of the path ``adj.propagate`` takes at width F."""
     lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
     if adj._tilegroup_plan(F):
-        return ("tile-group SpMM (512-row groups share fetched rows through LDS; fp16 hi/lo planes of X on "
-                "v_mfma_f32_32x32x16_f16, fp32 accumulation)", "k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine",
+        return ("tile-group SpMM (512-row groups share fetched rows through LDS; fp16 hi/lo planes of X, one scale per "
+                "feature column, on v_mfma_f32_32x32x16_f16, fp32 accumulation)",
+                "k_tg_amax + k_tg_state_init + k_tg_split (first hop only; later hops of a chain read the planes the "
+                "epilogue before them wrote) + k_tg_spmm + k_tg_combine + guarded plain-CSR fall-back (returns at once)",
                 "k_tg_spmm")
     R = lib.sgnn_rowgroup_config_for(adj.n, adj.nnz, F) if adj.use_rowgroup else 0
     if R:
@@ -131,13 +133,13 @@ def draw(workload, seed, device, max_degree=None, weight=None):
     return adj, X, row, col, t_gen, t_build
 
 
-def sub_record(workload, seed, device, max_degree=None, weight=None, min_region_s=0.3):
+def sub_record(workload, seed, device, max_degree=None, weight=None, order=1, min_region_s=0.3):
     """One benchmark shape beside the headline: ms per step, main kernel, roofline fraction."""
     import torch
     adj, X, row, col, t_gen, t_build = draw(workload, seed, device, max_degree, weight)
     del row, col
     n, F = X.shape
-    step = lambda: adj.propagate(X, 1)          # noqa: E731
+    step = lambda: adj.propagate(X, order)      # noqa: E731
     for _ in range(2):
         step()                                   # plans, buffers
     torch.cuda.synchronize()
@@ -151,13 +153,16 @@ def sub_record(workload, seed, device, max_degree=None, weight=None, min_region_
     b_alg = algorithmic_bytes(n, adj.nnz, F)
     max_deg = int((adj.rowptr[1:] - adj.rowptr[:-1]).max().item())
     key = workload + ("" if max_degree is None else f"_clip{max_degree}") + ("" if weight is None else f"_w{weight:g}")
-    rec = {"workload": key, "n": n, "nnz": adj.nnz, "F": F, "max_degree": max_deg,
+    if order > 1:
+        # a chain: X is split into planes once, every later hop reads what the epilogue before it wrote
+        key += f"_order{order}"
+    rec = {"workload": key, "n": n, "nnz": adj.nnz, "F": F, "order": order, "max_degree": max_deg,
            "weights": "unit" if weight is None else f"{weight:g} off the diagonal, 1 on it",
            "steps": steps, "ms_per_step": round(wall * 1e3 / steps, 4), "kernel": label.split(" (")[0],
            "main_kernel": main, "main_kernel_ms": None if k_ms is None else round(k_ms, 4),
-           "value": adj.nnz * F / (wall / steps), "algorithmic_bytes": b_alg,
-           "frac": b_alg / ((k_ms or ev_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-           "frac_whole_step": b_alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "value": adj.nnz * F * order / (wall / steps), "algorithmic_bytes": b_alg,
+           "frac": b_alg / ((k_ms or ev_ms / order) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "frac_whole_step": b_alg * order / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "traffic": load_traffic(key, main), "adjacency_build_ms": round(t_build * 1e3, 1)}
     if wall / steps < 0.5e-3:
         # a hop this short is bound by the host's launch calls: the same launches replayed from a
@@ -165,7 +170,7 @@ def sub_record(workload, seed, device, max_degree=None, weight=None, min_region_
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            Y = adj.propagate(X, 1)
+            Y = adj.propagate(X, order)
         w2, _, _, _ = timed_steps(graph.replay, steps, 3, device)
         rec["ms_per_step_graph_replay"] = round(w2 * 1e3 / steps, 4)
         del graph, Y
@@ -218,21 +223,60 @@ def cpu_baseline(row, col, X_dev, Y_dev, sample_edges, seed, budget_s=150.0):
     return out
 
 
-def copy_ceiling(device, mib=2048, reps=10):
-    """Read + write GB/s of a device-to-device copy of ``mib`` MiB: the streaming rate this
-    card delivers, to set beside the vendor peak."""
+def copy_ceiling(device, mib=512, reps=10):
+    """Read + write GB/s of a device-to-device copy of ``mib`` MiB through the library's own
+    streaming kernel (16 bytes per lane, sgnn_stream_copy_f32): the streaming rate this card
+    delivers, to set beside the vendor peak.  512 MiB is the size of the benchmark's operand
+    (561 MB in, 561 MB out); buffers of 2 GiB and more stream about 10 % slower."""
     import torch
+    from sgnn_amd import _lib
+    lib = _lib.load()
     src = torch.empty(mib << 18, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
+    st = _lib.current_stream(device)
     for _ in range(3):
-        dst.copy_(src)
+        _lib.check(lib.sgnn_stream_copy_f32(_lib.ptr(src), _lib.ptr(dst), src.numel(), st))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dst.copy_(src)
+        _lib.check(lib.sgnn_stream_copy_f32(_lib.ptr(src), _lib.ptr(dst), src.numel(), st))
     e1.record()
     torch.cuda.synchronize()
+    assert torch.equal(src[:4096], dst[:4096]) and torch.equal(src[-4096:], dst[-4096:])
     return 2.0 * src.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def exact_fp32_beside(adj, X, device):
+    """The same hop through the row-group kernel (fp32 operands all the way, no fp16 planes): what
+    a caller who cannot accept the planes' input rounding gets, and how far the two results are
+    apart (normwise, and element by element against |A_hat| |X|)."""
+    import torch
+    if not adj._tg:
+        return None
+    Y_tg = adj.propagate(X, 1)
+    adj.use_tilegroup = False
+    try:
+        Y_rg = adj.propagate(X, 1)
+        wall, ev_ms, k_ms, _ = timed_steps(lambda: adj.propagate(X, 1), 10, 2, device)
+        scale = adj.propagate(X.abs(), 1)
+    finally:
+        adj.use_tilegroup = None
+    out = {"fp32_exact_ms": round(ev_ms, 4), "fp32_exact_kernel_ms": None if k_ms is None else round(k_ms, 4),
+           "fp32_exact_kernel": "k_rg_spmm (row-group, fp32 vector adds)",
+           "tilegroup_vs_fp32_kernel_rel_err": float((Y_tg - Y_rg).norm() / Y_rg.norm()),
+           "tilegroup_vs_fp32_kernel_max_err_of_abs_sum": float(((Y_tg - Y_rg).abs() / scale.clamp_min(1e-30)).max())}
+    del Y_tg, Y_rg, scale
+    return out
+
+
+def load_step_composition(key):
+    """Average duration (ms) of every kernel of one step, from the committed rocprofv3 kernel
+    trace of this workload (profiles/step_composition.json, written by tools/profile_gpu.sh)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "step_composition.json")) as f:
+            return json.load(f)[key]
+    except Exception:
+        return None
 
 
 def sgnn_epoch(adj, X, device, max_iter, seed):
@@ -493,37 +537,64 @@ def main():
             torch.cuda.empty_cache()
         del row, col, X
         nnz, max_deg = info.pop("nnz"), info.pop("max_deg")
-        local = info.pop("_padj").local            # which kernel the rank-local multiply took (decided on first use)
+        padj = info.pop("_padj")
+        local = padj.local            # which kernel the rank-local multiply took (decided on first use)
         extra.update(info)
+        step()                                     # (sets padj.last_schedule for the schedule benchmarked)
+        # which schedule the timed steps run: "local-block" = own-columns block multiplied while the
+        # exchange runs, remote-columns block when it lands (with fp16 planes exchanged where the
+        # matrix-core kernel applies); "sliced" = feature slices pipelined; "none" = exchange, then multiply
+        extra["overlap"] = padj.last_schedule
         extra["collective"] = (f"{info['exchange']} among {info['exchange_ranks']} ranks, backend "
                                f"{dist.get_backend()} ({'gloo rehearsal on one GPU' if rehearsal else 'RCCL'}), "
                                f"world size {dist.get_world_size()}")
         if rank == 0:
-            log(f"headline: row partition over {info['exchange_ranks']} ranks; {extra['collective']}")
+            log(f"headline: row partition over {info['exchange_ranks']} ranks, overlap {extra['overlap']}; {extra['collective']}")
         if len(probed) > 1:
             extra["grid_probe_ms"] = probed
         lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
-        R = lib.sgnn_rowgroup_config_for(local.n_rows, local.adj.nnz, extra["features_per_rank"])
-        if getattr(local, "_tg", None):
-            kernel_path = "tile-group SpMM on the rank's rows (each rank splits the gathered operand)"
-            kernels_in_step = "k_row_scale + exchange + k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine"
+        planes = padj.last_schedule is not None and "planes" in padj.last_schedule
+        if planes:
+            Fr = extra["features_per_rank"]
+            extra["exchange_bytes_per_rank_per_hop"] = (
+                (padj.max_rows * padj.world if padj.halo is None else padj.halo["n_recv"]) * ((Fr + 127) // 128 * 128) * 4)
+            kernel_path = ("tile-group SpMM on the rank's own-columns and remote-columns blocks; every rank splits only "
+                           "its own rows and fp16 planes travel, one exchange per 128-feature slice")
+            kernels_in_step = ("k_tg_amax + all_reduce(max) + k_tg_split (own rows) + exchange || k_tg_spmm (own columns) "
+                               "+ k_tg_spmm (remote columns, adds the own-columns sums) + k_tg_combine")
             main_kernel = "k_tg_spmm"
         else:
-            kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
-            kernels_in_step = "k_row_scale + exchange + " + ("k_rg_spmm + k_rg_combine" if R else "k_spmm")
-            main_kernel = "k_rg_spmm" if R else "k_spmm"
+            blk = padj.remote if (padj.last_schedule == "local-block" and padj.remote is not None) else local
+            R = lib.sgnn_rowgroup_config_for(blk.n_rows, blk.adj.nnz, extra["features_per_rank"])
+            if getattr(local, "_tg", None) and padj.last_schedule in ("none", "sliced"):
+                kernel_path = "tile-group SpMM on the rank's rows (each rank splits the gathered operand)"
+                kernels_in_step = "k_row_scale + exchange + k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine"
+                main_kernel = "k_tg_spmm"
+            else:
+                kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
+                kernels_in_step = "k_row_scale + exchange + " + ("k_rg_spmm + k_rg_combine" if R else "k_spmm")
+                if padj.last_schedule == "local-block":
+                    kernels_in_step = ("k_row_scale + exchange || own-columns " + ("k_rg_spmm" if R else "k_spmm")
+                                       + " + remote-columns " + ("k_rg_spmm" if R else "k_spmm") + " + k_add_scale")
+                main_kernel = "k_rg_spmm" if R else "k_spmm"
 
     wall, ev_ms, k_ms, k_n = timed_steps(step, args.steps, args.warmup, device, world, dist if world > 1 else None)
 
-    copy_gbps = None
+    copy_gbps = copy_gbps_2g = None
+    exact = None
     epoch = epoch_gae = None
     others = []
     cpu = None
     if rank == 0 and world == 1:
         try:
             copy_gbps = copy_ceiling(device)
+            copy_gbps_2g = copy_ceiling(device, mib=2048)
         except Exception as exc:
             log(f"copy ceiling not measured: {exc}")
+        try:
+            exact = exact_fp32_beside(adj, X, device) if not args.no_extras else None
+        except Exception as exc:
+            exact = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:
             try:
                 Y = adj.propagate(X, 1)
@@ -549,12 +620,13 @@ def main():
         if args.workload == "reddit" and args.max_degree is None and args.weight is None and not args.no_extras:
             del adj, X
             torch.cuda.empty_cache()
-            for wl, md, wt in (("reddit", 22000, None), ("reddit", None, 2.0), ("reddit", 22000, 2.0),
-                               ("reddit128", None, None), ("products", None, None), ("rmat10m", None, None),
-                               ("pubmed", None, None)):
-                log(f"other shapes: {wl} max_degree={md} weight={wt}")
+            for wl, md, wt, od in (("reddit", 22000, None, 1), ("reddit", None, 2.0, 1), ("reddit", 22000, 2.0, 1),
+                                   ("reddit", None, None, 2), ("reddit128", None, None, 1), ("products", None, None, 1),
+                                   ("products", None, None, 2), ("rmat10m", None, None, 1), ("rmat10m", None, None, 2),
+                                   ("pubmed", None, None, 1)):
+                log(f"other shapes: {wl} max_degree={md} weight={wt} order={od}")
                 try:
-                    others.append(sub_record(wl, args.seed, device, md, wt))
+                    others.append(sub_record(wl, args.seed, device, md, wt, od))
                 except Exception as exc:
                     others.append({"workload": wl, "error": f"{type(exc).__name__}: {exc}"})
     if rank == 0:
@@ -593,8 +665,8 @@ def main():
                         f"row partition: {extra['row_ranks']} row blocks over {world} GPUs, all-gather of the scaled "
                         "X blocks",
                 "arithmetic": "fp32 in, fp32 out, fp32 accumulation; the tile-group kernel feeds the matrix cores X as "
-                              "two fp16 planes (hi + lo/2048 at a power-of-two scale) that reproduce each fp32 input to "
-                              "2^-22 relative; operands they cannot represent take the plain fp32 kernel"
+                              "two fp16 planes (hi + lo/2048 at one power-of-two scale per feature column) that reproduce each fp32 "
+                              "input to 2^-22 relative; operands they cannot represent take the plain fp32 kernel"
                               if main_kernel == "k_tg_spmm" else "fp32 throughout",
                 "graph_gen_s": round(t_gen, 2),
                 "kernel": kernel_path,
@@ -619,8 +691,14 @@ def main():
             },
         }
         roof = out["roofline"]
+        if exact:
+            roof.update(exact)
+        comp = load_step_composition(key) if world == 1 else None
+        if comp:
+            roof["step_composition_ms"] = comp          # from the committed kernel trace of this workload
         if copy_gbps:                                         # what a streaming copy reaches on this card
-            roof["copy_ceiling"] = copy_gbps
+            roof["copy_ceiling"] = copy_gbps                  # 512 MiB buffers, hand-written float4 copy
+            roof["copy_ceiling_2GiB_buffers"] = copy_gbps_2g
             roof["frac_of_copy"] = achieved / copy_gbps
         if roof["traffic"]:                                   # bytes the L2s fetched or wrote, per launch
             roof["fabric_GBps"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9

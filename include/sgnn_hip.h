@@ -406,6 +406,11 @@ int sgnn_row_scale_f32(int64_t n, int64_t F, const float* scale,
 int sgnn_add_scale_f32(int64_t n, int64_t F, const float* a, int64_t lda, const float* b, int64_t ldb,
                        const float* scale, int twice, float* out, int64_t ldout, void* stream);
 
+/* Measurement aid, no counterpart in the reference: dst[0, count) <- src, 16 bytes per lane, as a
+ * yardstick of what the card streams (read + write) beside the vendor's HBM peak.  count must be
+ * a multiple of 4, both buffers 16-byte aligned and disjoint. */
+int sgnn_stream_copy_f32(const float* src, float* dst, int64_t count, void* stream);
+
 /* sampling flags */
 #define SGNN_SAMPLE_SKIP_SELF  1   /* write 0 where idx[i] == idx[j]: sample the matrix without its diagonal */
 

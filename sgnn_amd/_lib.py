@@ -85,6 +85,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
                                          c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sgnn_row_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "sgnn_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "sgnn_add_scale_f32": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                    c_int64, c_void_p]),
     "sgnn_gae_targets_f32": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -369,6 +369,16 @@ __global__ __launch_bounds__(256) void k_add_scale(int64_t n, int64_t F, const f
   }
 }
 
+// dst <- src, 16 bytes per lane, non-temporal loads and stores, four workgroups per CU walking the
+// buffers with a grid stride: the fastest of the forms swept in tools/proto/copy_probe.hip (more
+// loads in flight per lane or a larger grid stream 10-25 % slower on this card).  A yardstick for
+// the roofline: what the card streams, read plus write.
+__global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n4; i += stride)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 struct SpmmWs {
   int32_t *counters, *seg_row, *seg_k, *long_row, *long_slot;
   float* partial;
@@ -683,6 +693,18 @@ int sgnn_row_scale_f32(int64_t n, int64_t F, const float* scale, const float* in
   if (!scale || !in || !out) return fail(SGNN_ERR_INVALID, "null pointer");
   hipLaunchKernelGGL(k_row_scale, dim3(unsigned((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      n, F, scale, in, ldin, out, ldout);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+int sgnn_stream_copy_f32(const float* src, float* dst, int64_t count, void* stream) {
+  if (count < 0) return fail(SGNN_ERR_INVALID, "negative size");
+  if (count == 0) return SGNN_OK;
+  if (!src || !dst) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (count % 4 || reinterpret_cast<uintptr_t>(src) % 16 || reinterpret_cast<uintptr_t>(dst) % 16)
+    return fail(SGNN_ERR_INVALID, "count must be a multiple of 4 and both buffers 16-byte aligned");
+  hipLaunchKernelGGL(k_stream_copy, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), count / 4);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
