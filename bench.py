@@ -18,9 +18,11 @@ classification stack and one of the clustering (auto-encoder) stack at the refer
 
 N > 1 (launched by torch.distributed.run, one rank per GPU) splits the same job
 over the ranks (strong scaling).  The headline is always the pure row partition:
-every rank owns a block of rows of the graph and all N ranks all-gather the scaled
-row blocks of X over RCCL before their SpMM (plain, or overlapped in feature slices —
-whichever is faster; both are the same partition).  Grids that also split the feature
+every rank owns a block of rows of the graph, multiplies its own-columns block while the
+other ranks' rows of the operand travel over RCCL (as fp16 planes, one all-gather per
+128-feature slice, where the matrix-core kernel applies; as fp32 rows otherwise) and its
+remote-columns block when they have landed (``config.overlap`` names the schedule that
+ran; ``--slices k`` lets the feature-sliced pipeline compete).  Grids that also split the feature
 columns (feature_groups x row_ranks) are timed for a few steps each and reported as
 ``grid_probe_ms`` extras only.
 """
@@ -387,8 +389,10 @@ def main():
     ap.add_argument("--max-degree", type=int, default=None, help="clip hub degree (real Reddit's is ~21.7k)")
     ap.add_argument("--weight", type=float, default=None,
                     help="off-diagonal weight (2.0 = the reference's A + A^T Reddit adjacency, data_loader.py:75)")
-    ap.add_argument("--slices", type=int, default=2,
-                    help="N > 1: feature slices of the exchange/SpMM pipeline (1 = no overlap)")
+    ap.add_argument("--slices", type=int, default=1,
+                    help="N > 1: also let the feature-sliced exchange/SpMM pipeline (fp32 rows, one block) of this many "
+                         "slices compete with the default schedule (own-columns block multiplied while the exchange "
+                         "runs); 1 = default schedule only")
     ap.add_argument("--feature-groups", type=int, default=0,
                     help="N > 1: extra grids to probe beside the row partition: 0 = every divisor of N, 1 = none, "
                          "k = only k feature groups")
