@@ -79,25 +79,26 @@ static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned s
 static_assert(kTableBytes + kWaves * kStageOutBytes <= kLdsBytes, "the write-out staging must fit the ring");
 
 std::atomic<int> g_seg_stages{0};     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
-std::atomic<int> g_order_cols{0};     // > 0: work items ordered by column blocks of this width; 0: longest first (sgnn_tune_set("tg_order", v))
-std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only; results are then wrong
+std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_order", v)): 0 = longest first; < 0 = length buckets, then column block, then group; > 0 = by column blocks of this width
+std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only (results are then wrong); 128 = one workgroup per unit, 256 = one work counter per XCD instead of one for the launch
 
 struct TgState {          // device words that carry an operand's scales and its fall-back flag to the SpMM that reads it
   uint32_t amax_all;      // bit pattern of the largest |element| over all features (diagnostics)
   uint32_t flag;          // != 0: the operand cannot go through the fp16 planes (1: an element, 2: too many tiny ones, 4: plan mismatch, 8: inherited from the hop before)
   uint32_t rsv[2];
   uint32_t tiny;          // nonzero elements that keep fewer than 17 of their bits in the planes
-  uint32_t queue;         // next work index of the running SpMM launch (zeroed by the SpMM call)
+  uint32_t rsv2;
   uint32_t tiny_limit;    // more tiny elements than this: fall back
-  uint32_t pad;
+  uint32_t queue;         // next work index of the running SpMM launch (this word and the eight behind it are zeroed by the SpMM call)
+  uint32_t xcd_queue[8];  // the same, one per XCD (see k_tg_spmm)
   // [Fpad] per feature, the bit pattern of its largest |element| as measured while the operand
   // was written, followed by [Fpad] the bound its scale was derived from.  An operand split
   // from fp32 is measured first, so the two agree; one written by the epilogue of the hop
   // before uses what was known when that hop started (bound_of) and is measured on the way out.
   uint32_t amax[1];
 };
-constexpr size_t kStateHead = 32;
-static_assert(offsetof(TgState, amax) == kStateHead, "state header is eight words");
+constexpr size_t kStateHead = 64;
+static_assert(offsetof(TgState, amax) == kStateHead, "state header is sixteen words");
 __device__ __forceinline__ uint32_t* bound_of(TgState* s, int Fpad) { return s->amax + Fpad; }
 __device__ __forceinline__ const uint32_t* bound_of(const TgState* s, int Fpad) { return s->amax + Fpad; }
 
@@ -446,13 +447,30 @@ __global__ void k_tg_items(int64_t G, const uint32_t* __restrict__ gns, const ui
 // (measured on the Reddit shape against ordering by the column block an item starts in, which
 // is what the row-group kernel's L2 reuse wanted: 5.5-5.65 ms per hop against 5.9; this
 // kernel's reuse happens inside a group, and the last long items of a launch idle the chip).
+// Ties go by item number, i.e. the pieces of one group's list follow each other and CUs that
+// start together walk different stretches of the column space.  The opposite was tried -- lengths
+// compared in buckets of 32 stages and, inside a bucket, items ordered by the column block they
+// start in, then by group, so that neighbours in the order fetch nearly the same rows of X at the
+// same pace (order_cols < 0), alone and with the kernel handing runs of 32 neighbours to the CUs of
+// one XCD (tg_mode bit 256): on the Reddit shape the main kernel takes 4.72 ms instead of 4.63
+// with the order alone and 4.95 ms with the per-XCD runs -- CUs that ask for the same rows at the
+// same moment queue up at the same L2 channel and the same memory channel behind it, where
+// requests spread over the column space do not; the ogbn-products shape gains 2.7 % (3.84
+// against 3.94 ms).  (order_cols > 0: by column blocks of that width alone.)
 __global__ void k_tg_item_keys(int64_t items, const int32_t* __restrict__ tmp, int64_t cap,
                                const int32_t* __restrict__ stage_col, int order_cols, uint64_t* __restrict__ keys) {
   int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (it >= items) return;
   const int64_t s0 = tmp[cap + it];
-  if (order_cols <= 0) {
-    keys[it] = (uint64_t(0x7fffffff - (tmp[2 * cap + it] - int32_t(s0))) << 32) | uint64_t(it);
+  const int64_t len = tmp[2 * cap + it] - int32_t(s0);
+  if (order_cols == 0) {
+    keys[it] = (uint64_t(0x7fffffff - len) << 32) | uint64_t(it);
+    return;
+  }
+  if (order_cols < 0) {
+    const uint64_t lb = uint64_t(0xFFFF) - uint64_t(len / 32 < 0xFFFF ? len / 32 : 0xFFFF);
+    const uint64_t cb = len > 0 ? uint64_t(stage_col[s0 * kStageCols]) >> 12 : 0;
+    keys[it] = (lb << 48) | ((cb < 0xFFFF ? cb : 0xFFFF) << 32) | uint64_t(it);
     return;
   }
   keys[it] = (uint64_t(stage_col[s0 * kStageCols] / order_cols) << 32) | uint64_t(it);
@@ -1277,10 +1295,34 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   // pair).  Every wavefront leaves through the same test of b.
   int* next = reinterpret_cast<int*>(smem + kTicketOff);   // behind the pattern table
   int prev = -1;
+  // Which units a workgroup takes: the next of the launch order (one counter).  Diagnostic
+  // alternative (mode bit 256, see k_tg_item_keys for what it measured): the order dealt out in runs
+  // of 32 units (an XCD has 32 CUs), run r to XCD r mod 8, a workgroup taking the next unit of its
+  // own XCD's runs (one counter per XCD) and, when those are finished, of the other XCDs'.
+  const int xcd = int(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);   // XCC_ID
+  const bool by_xcd = (a.mode & 256) != 0;
+  int victim = 0;   // how many other XCDs' queues this workgroup has found empty
   for (;;) {
     int b = blockIdx.x;
     if (!(a.mode & 128)) {
-      if (threadIdx.x == 0) *next = int(atomicAdd(a.queue, 1u));
+      if (threadIdx.x == 0) {
+        int t = total;
+        if (by_xcd) {
+          // ticket k of queue q is unit k % 32 of the queue's run k / 32, i.e. of run (k / 32) * 8 + q
+          // of the launch; tickets only grow, so a queue whose ticket lies past the end is finished
+          while (victim < 8) {
+            const int q = (xcd + victim) & 7;
+            const int k = int(atomicAdd(&a.state->xcd_queue[q], 1u));
+            t = ((k >> 5) * 8 + q) * 32 + (k & 31);
+            if (t < total) break;
+            t = total;
+            ++victim;
+          }
+        } else {
+          t = int(atomicAdd(a.queue, 1u));
+        }
+        *next = t;
+      }
       __syncthreads();
       b = __builtin_amdgcn_readfirstlane(*next);
       __syncthreads();   // everyone has read it before the next round writes it; the last item's LDS reads are over
@@ -1457,7 +1499,7 @@ dim3 blocks_for(int64_t items, unsigned T = 256) { return dim3(unsigned((items +
 namespace sgnn {
 void set_tilegroup_mode(int m) { g_tg_mode = m; }
 void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 0; }
-void set_tilegroup_order(int cols) { g_order_cols = cols > 0 ? cols : 0; }
+void set_tilegroup_order(int cols) { g_order_cols = cols; }
 }  // namespace sgnn
 
 extern "C" {
@@ -1756,7 +1798,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
     cus_of[dev].store(n_cus, std::memory_order_release);
   }
   if (planes_out != nullptr) HIP_TRY(hipMemsetAsync(state_out, 0, sgnn_tilegroup_state_bytes(F), st));
-  HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(a.queue, 0, 9 * sizeof(uint32_t), st));   // the work counters: one for the launch, one per XCD
   // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
   sgnn::kernel_timer_begin(st);
   const int64_t wgs = (items * slices < n_cus || (a.mode & 128)) ? items * slices : n_cus;
