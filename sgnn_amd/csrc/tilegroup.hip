@@ -101,6 +101,12 @@ constexpr size_t kStateHead = 64;
 static_assert(offsetof(TgState, amax) == kStateHead, "state header is sixteen words");
 __device__ __forceinline__ uint32_t* bound_of(TgState* s, int Fpad) { return s->amax + Fpad; }
 __device__ __forceinline__ const uint32_t* bound_of(const TgState* s, int Fpad) { return s->amax + Fpad; }
+// behind the two arrays: kAmaxBlocks x Fpad words in which the workgroups of the measuring pass
+// leave their maxima (one atomic per feature and workgroup on the same few hundred words took a
+// third of that pass)
+constexpr int kAmaxBlocks = 512;
+__device__ __forceinline__ uint32_t* scratch_of(TgState* s, int Fpad) { return s->amax + 2 * Fpad; }
+inline size_t tg_state_live_bytes(int64_t Fpad) { return kStateHead + size_t(2 * Fpad) * sizeof(uint32_t); }
 
 // ---- plan ------------------------------------------------------------------------
 struct TgPlan {
@@ -498,7 +504,7 @@ __global__ void k_tg_item_place(int64_t items, const uint64_t* __restrict__ keys
 // value) into state->amax.  A workgroup's threads lie along the features, V = 1 or 2 consecutive
 // ones per thread; rows are walked four at a time so that four loads are in flight per lane; a
 // narrow row leaves room for several row quadruples side by side (`subs`), folded through LDS.
-__global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, const float* __restrict__ scale_row,
+__global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, int Fpad, const float* __restrict__ scale_row,
                                                  const float* __restrict__ X, int64_t ldx, TgState* __restrict__ state) {
   __shared__ uint32_t smax[2048];
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
@@ -546,8 +552,9 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, const fl
       __syncthreads();
     }
     if (sub == 0 && f < F) {
-      if (m0) atomicMax(&state->amax[f], m0);
-      if (V == 2 && f + 1 < F && m1) atomicMax(&state->amax[f + 1], m1);
+      uint32_t* mine = scratch_of(state, Fpad) + int64_t(blockIdx.x) * Fpad;
+      mine[f] = m0;
+      if (V == 2 && f + 1 < F) mine[f + 1] = m1;
       all = m0 > all ? m0 : all;
       all = m1 > all ? m1 : all;
     }
@@ -558,6 +565,42 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, const fl
     all = o > all ? o : all;
   }
   if ((threadIdx.x & (kWave - 1)) == 0 && all) atomicMax(&state->amax_all, all);
+}
+
+// the workgroups' maxima folded per feature: a workgroup takes 64 features, its 16 wavefronts
+// every 16th workgroup's row of the scratch (lanes along the features, several loads in flight)
+__global__ __launch_bounds__(1024) void k_tg_amax_fold(int F, int Fpad, int blocks, TgState* __restrict__ state) {
+  __shared__ uint32_t part[16][64];
+  const int fx = threadIdx.x & 63, by = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fx;
+  uint32_t m = 0;
+  if (f < F) {
+    const uint32_t* p = scratch_of(state, Fpad) + f;
+    uint32_t m1 = 0, m2 = 0, m3 = 0;
+    int b = by;
+    for (; b + 48 < blocks; b += 64) {
+      const uint32_t v0 = p[int64_t(b) * Fpad], v1 = p[int64_t(b + 16) * Fpad];
+      const uint32_t v2 = p[int64_t(b + 32) * Fpad], v3 = p[int64_t(b + 48) * Fpad];
+      m = v0 > m ? v0 : m;
+      m1 = v1 > m1 ? v1 : m1;
+      m2 = v2 > m2 ? v2 : m2;
+      m3 = v3 > m3 ? v3 : m3;
+    }
+    for (; b < blocks; b += 16) {
+      const uint32_t v = p[int64_t(b) * Fpad];
+      m = v > m ? v : m;
+    }
+    m = m1 > m ? m1 : m;
+    m2 = m3 > m2 ? m3 : m2;
+    m = m2 > m ? m2 : m;
+  }
+  part[by][fx] = m;
+  __syncthreads();
+  if (by == 0 && f < F) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = part[i][fx] > m ? part[i][fx] : m;
+    state->amax[f] = m;
+  }
 }
 
 // the power of two that brings amax into [2^14, 2^15)
@@ -1665,7 +1708,7 @@ size_t sgnn_tilegroup_planes_bytes(int64_t n_cols, int64_t F) {
 size_t sgnn_tilegroup_state_bytes(int64_t F) {
   if (F <= 0) return 0;
   const int64_t Fpad = (F + kSlice - 1) / kSlice * kSlice;
-  return align_up(kStateHead + size_t(2 * Fpad) * sizeof(uint32_t));
+  return align_up(tg_state_live_bytes(Fpad) + size_t(kAmaxBlocks) * Fpad * sizeof(uint32_t));
 }
 
 int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* state,
@@ -1675,12 +1718,16 @@ int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const 
   if (!X || !state) return fail(SGNN_ERR_INVALID, "null pointer");
   if (ldx < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
   TgState* s = static_cast<TgState*>(state);
-  HIP_TRY(hipMemsetAsync(s, 0, sgnn_tilegroup_state_bytes(F), st));
+  const int Fpad = int((F + kSlice - 1) / kSlice * kSlice);
+  HIP_TRY(hipMemsetAsync(s, 0, tg_state_live_bytes(Fpad), st));
   const int64_t per_row = (F + 1) / 2;
   const unsigned T = unsigned(per_row >= 1024 ? 1024 : (per_row <= 256 ? 256 : (per_row + kWave - 1) / kWave * kWave));
-  // every workgroup ends in one atomic per feature: few workgroups, each with many rows
+  // two workgroups per CU, each with many rows; their maxima meet in the fold kernel
   const int64_t quads = (n + 3) / 4;
-  hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(quads < 512 ? quads : 512)), dim3(T), 0, st, n, F, scale_row, X, ldx, s);
+  const int blocks = int(quads < kAmaxBlocks ? quads : kAmaxBlocks);
+  hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(blocks)), dim3(T), 0, st, n, F, Fpad, scale_row, X, ldx, s);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tg_amax_fold, dim3(unsigned((F + 63) / 64)), dim3(1024), 0, st, int(F), Fpad, blocks, s);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
@@ -1797,7 +1844,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
     if (n_cus <= 0) n_cus = 256;
     cus_of[dev].store(n_cus, std::memory_order_release);
   }
-  if (planes_out != nullptr) HIP_TRY(hipMemsetAsync(state_out, 0, sgnn_tilegroup_state_bytes(F), st));
+  if (planes_out != nullptr) HIP_TRY(hipMemsetAsync(state_out, 0, tg_state_live_bytes(slices * kSlice), st));
   HIP_TRY(hipMemsetAsync(a.queue, 0, 9 * sizeof(uint32_t), st));   // the work counters: one for the launch, one per XCD
   // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
   sgnn::kernel_timer_begin(st);
@@ -1809,7 +1856,7 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
     const int quads = tg_combine_quads(a.F, a.Fpad, planes_out != nullptr);
     // 64 workgroups per split group where there are few groups, fewer where there are thousands
     // (every workgroup ends in one atomic per feature when it writes planes)
-    const unsigned gy = unsigned(long_groups >= 4096 ? 1 : (4096 / long_groups > 64 ? 64 : 4096 / long_groups));
+    const unsigned gy = unsigned(long_groups >= 16384 ? 1 : (16384 / long_groups > 64 ? 64 : 16384 / long_groups));
     hipLaunchKernelGGL(k_tg_combine, dim3(unsigned(long_groups), gy), dim3(tg_combine_threads(quads)), 0, st, a);
     HIP_TRY(hipGetLastError());
   }

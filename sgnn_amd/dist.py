@@ -507,7 +507,7 @@ class PartitionedAdj:
         # operand 0: per-feature maxima of the local rows, agreed on by all ranks, then the local split
         _lib.check(lib.sgnn_tilegroup_amax_f32(rows, F, _lib.ptr(dinv), _lib.ptr(X_local), X_local.stride(0),
                                                _lib.ptr(states[0]), st))
-        amax = states[0, 8:8 + Fpad]
+        amax = states[0, _lib.TG_STATE_HEAD_WORDS:_lib.TG_STATE_HEAD_WORDS + Fpad]
         if dist.get_backend(self.group) == "gloo":
             host = amax.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
@@ -550,7 +550,8 @@ class PartitionedAdj:
                 None if last else _lib.ptr(nxt), n_cols, lo, None if last else _lib.ptr(states[h + 1]), 0, st))
         # one agreement per call: did every rank's every operand go through the planes?
         head = states[:order, :8].cpu()           # synchronises
-        refused = bool((head[:, 1] != 0).any() or (head[:, 4] > head[:, 6]).any())
+        refused = bool((head[:, _lib.TG_STATE_FLAG] != 0).any()
+                       or (head[:, _lib.TG_STATE_TINY] > head[:, _lib.TG_STATE_TINY_LIMIT]).any())
         if self._agree(1 if refused else 0, dev, dist.ReduceOp.MAX):
             return None
         return out
