@@ -1401,7 +1401,8 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
 __host__ __device__ inline int tg_combine_quads(int F, int Fpad, bool to_planes) { return ((to_planes ? Fpad : F) + 3) / 4; }
 inline unsigned tg_combine_threads(int quads) {
   if (quads >= 1024) return 1024;
-  const int rows = 256 / quads > 0 ? 256 / quads : 1;
+  const int fit = 512 / quads;                // rows side by side
+  const int rows = fit > 8 ? 8 : (fit < 1 ? 1 : fit);
   const int t = quads * rows;
   return unsigned(t < 64 ? 64 : t);
 }
@@ -1430,15 +1431,17 @@ __global__ __launch_bounds__(1024) void k_tg_combine(TgArgs a) {
   for (int q = threadIdx.x % quads; q < quads && int(threadIdx.x) < quads * rows_par; q += int(blockDim.x) >= quads ? quads : int(blockDim.x)) {
     const int f4 = q * 4;
     uint32_t mx[4] = {0, 0, 0, 0};
-    uint32_t nb[4];
-    float inv_in[4];
+    uint32_t nb[4] = {0, 0, 0, 0};
+    float inv_in[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (to_planes || (a.corr != nullptr && a.X == nullptr)) {   // (uniform) the features' scales are needed only then
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int f = f4 + j;
-      const uint32_t bnd = f < a.F ? bound_of(a.state, a.Fpad)[f] : 0u;
-      nb[j] = (to_planes && a.adapt && f < a.F) ? a.state->amax[f] : bnd;
-      const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
-      inv_in[j] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);
+      for (int j = 0; j < 4; ++j) {
+        const int f = f4 + j;
+        const uint32_t bnd = f < a.F ? bound_of(a.state, a.Fpad)[f] : 0u;
+        nb[j] = (to_planes && a.adapt && f < a.F) ? a.state->amax[f] : bnd;
+        const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
+        inv_in[j] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);
+      }
     }
     for (int r = int(threadIdx.x) / quads; r < my_rows; r += rows_par) {
       const int rr = int(blockIdx.y) + r * int(gridDim.y);
