@@ -59,9 +59,9 @@ int sgnn_version(void);
  * "unroll" = row fetches issued back to back (2 or 4), "rg_seg" = merged columns per
  * row-group work item, "rg_R" = rows per group, 8 or 16, "rg_order" = width of the column blocks the work
  * items are ordered by (all three affect plans built afterwards), "tg_seg" = stages per
- * tile-group work item, "tg_order" = width of the column blocks tile-group work items are
- * ordered by (0: longest item first, the default), "tg_mode" = diagnostic switches of the
- * tile-group kernel,
+ * tile-group work item, "tg_order" = order of the tile-group work items (0: chosen by the
+ * graph, the default; 1: longest first; -1: neighbours together; > 1: by column blocks of
+ * this width), "tg_mode" = diagnostic switches of the tile-group kernel,
  * "time_kernel" = 1/0 turns the kernel timer on/off (see sgnn_kernel_time_ms); value 0
  * restores the built-in policy.  No reference counterpart. */
 int sgnn_tune_set(const char* key, int value);

@@ -79,8 +79,8 @@ static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned s
 static_assert(kTableBytes + kWaves * kStageOutBytes <= kLdsBytes, "the write-out staging must fit the ring");
 
 std::atomic<int> g_seg_stages{0};     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
-std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_order", v)): 0 = longest first; < 0 = length buckets, then column block, then group; > 0 = by column blocks of this width
-std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only (results are then wrong); 128 = one workgroup per unit, 256 = one work counter per XCD instead of one for the launch
+std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_order", v)): 0 = chosen by the graph; 1 = longest first; < 0 = neighbours together (length buckets, then column block, then group); > 1 = by column blocks of this width
+std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only (results are then wrong); 128 = one workgroup per unit, 256 / 1024 = one work counter per XCD / one for the launch whatever the plan says
 
 struct TgState {          // device words that carry an operand's scales and its fall-back flag to the SpMM that reads it
   uint32_t amax_all;      // bit pattern of the largest |element| over all features (diagnostics)
@@ -110,7 +110,7 @@ inline size_t tg_state_live_bytes(int64_t Fpad) { return kStateHead + size_t(2 *
 
 // ---- plan ------------------------------------------------------------------------
 struct TgPlan {
-  int64_t* counts;        // [8] merged, stages, steps, items, partial slots, long groups, stages per item
+  int64_t* counts;        // [16] merged, stages, steps, items, partial slots, long groups, stages per item, rows, neighbour order (0 / 1)
   int32_t* grows;         // [G * 512] row of (group, slot), -1 = none
   int32_t* gstage0;       // [G + 1] first stage of every group
   int32_t* stage_col;     // [stages * 64] columns of a stage (tail of a group's last stage: its first column again)
@@ -128,7 +128,7 @@ TgPlan carve_tg_plan(void* base, int64_t n_rows, int64_t stages, int64_t steps, 
   TgPlan p{};
   Carver c(base);
   p.G = (n_rows + kRows - 1) / kRows;
-  p.counts = c.take<int64_t>(8);
+  p.counts = c.take<int64_t>(16);
   p.grows = c.take<int32_t>(size_t(p.G) * kRows);
   p.gstage0 = c.take<int32_t>(size_t(p.G) + 1);
   p.stage_col = c.take<int32_t>(size_t(stages) * kStageCols + 3 * kStageCols);   // a stage's DMA also brings the next two stages' ids
@@ -172,7 +172,7 @@ TgBuild carve_tg_build(void* base, int64_t n_rows, int64_t nnz) {
   w.cap_stages = nnz / kStageCols + w.G + 1;
   w.cap_runs = w.cap_stages * kSubs;
   w.cap_items = w.G + w.cap_stages / 8 + 1;   // a group is cut only into pieces of at least 8 stages
-  w.counts = c.take<int64_t>(8);
+  w.counts = c.take<int64_t>(16);
   w.dkey_a = c.take<uint32_t>(n_rows);
   w.dkey_b = c.take<uint32_t>(n_rows);
   w.drow_a = c.take<uint32_t>(n_rows);
@@ -449,37 +449,48 @@ __global__ void k_tg_items(int64_t G, const uint32_t* __restrict__ gns, const ui
   }
 }
 
-// Launch order: longest item first, so that the tail of the launch is made of short items
-// (measured on the Reddit shape against ordering by the column block an item starts in, which
-// is what the row-group kernel's L2 reuse wanted: 5.5-5.65 ms per hop against 5.9; this
-// kernel's reuse happens inside a group, and the last long items of a launch idle the chip).
-// Ties go by item number, i.e. the pieces of one group's list follow each other and CUs that
-// start together walk different stretches of the column space.  The opposite was tried -- lengths
-// compared in buckets of 32 stages and, inside a bucket, items ordered by the column block they
-// start in, then by group, so that neighbours in the order fetch nearly the same rows of X at the
-// same pace (order_cols < 0), alone and with the kernel handing runs of 32 neighbours to the CUs of
-// one XCD (tg_mode bit 256): on the Reddit shape the main kernel takes 4.72 ms instead of 4.63
-// with the order alone and 4.95 ms with the per-XCD runs -- CUs that ask for the same rows at the
-// same moment queue up at the same L2 channel and the same memory channel behind it, where
-// requests spread over the column space do not; the ogbn-products shape gains 2.7 % (3.84
-// against 3.94 ms).  (order_cols > 0: by column blocks of that width alone.)
+// Launch order.  Two orders, chosen by how much the graph's rows share (tools/xcd_probe.py,
+// profiles/r03_tilegroup_item_order_and_xcd_queues.txt):
+// * longest item first, ties by item number (the pieces of one group's list follow each other, so
+//   CUs that start together walk different stretches of the column space), one work counter for
+//   the launch.  The tail of the launch is made of short items (against ordering by the column
+//   block an item starts in, which is what the row-group kernel's L2 reuse wanted: 5.5-5.65 ms
+//   per hop against 5.9 on the Reddit shape).
+// * neighbours together: lengths compared in buckets of 32 stages and, inside a bucket, items by
+//   the 4096-column block they start in, then by group -- neighbours in this order are the same
+//   stretch of the lists of adjacent, equally dense groups, which fetch nearly the same rows of X
+//   at the same pace -- and the kernel hands runs of 32 neighbours to the CUs of one XCD (one work
+//   counter per XCD), whose L2 then serves most of a row's fetches after the first.
+// On the Reddit shape the second cuts the bytes that cross the L2's fabric side by 40 % (fetch
+// counter 10.87 -> 6.56 M KiB per launch, L2 hits 98.7 -> 167.7 M) and is 4 % SLOWER (main kernel
+// 4.88 against 4.69 ms; the order alone, with one counter: 4.77 ms, 26 % fewer bytes): that
+// kernel is not bound by what crosses the fabric, and CUs that ask for the same rows in the same
+// microsecond queue at one L2 channel.  On the sparse shapes, whose kernel time IS the fabric's
+// gather rate, it wins: ogbn-products 3.76 against 4.02 ms, R-MAT 10 M 10.7 against 11.7 ms.
+// Hence the rule: neighbours together where a fetched row serves fewer than 4 stored entries on
+// average (merged * 4 > nnz: products 2.35, R-MAT 10 M 1.6; the Reddit shape has 9.5).
 __global__ void k_tg_item_keys(int64_t items, const int32_t* __restrict__ tmp, int64_t cap,
-                               const int32_t* __restrict__ stage_col, int order_cols, uint64_t* __restrict__ keys) {
+                               const int32_t* __restrict__ stage_col, int order_cols, int64_t nnz,
+                               int64_t* __restrict__ plan_counts, uint64_t* __restrict__ keys) {
   int64_t it = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (it >= items) return;
   const int64_t s0 = tmp[cap + it];
   const int64_t len = tmp[2 * cap + it] - int32_t(s0);
-  if (order_cols == 0) {
+  // order_cols 0: by the graph -- neighbours together where a fetched row serves fewer than 4 stored
+  // entries on average (see above); 1: longest first; < 0: neighbours together; > 1: column blocks
+  const bool neighbours = order_cols < 0 || (order_cols == 0 && plan_counts[0] * 4 > nnz);
+  if (it == 0) plan_counts[8] = neighbours ? 1 : 0;
+  if (order_cols > 1) {
+    keys[it] = (uint64_t(stage_col[s0 * kStageCols] / order_cols) << 32) | uint64_t(it);
+    return;
+  }
+  if (!neighbours) {
     keys[it] = (uint64_t(0x7fffffff - len) << 32) | uint64_t(it);
     return;
   }
-  if (order_cols < 0) {
-    const uint64_t lb = uint64_t(0xFFFF) - uint64_t(len / 32 < 0xFFFF ? len / 32 : 0xFFFF);
-    const uint64_t cb = len > 0 ? uint64_t(stage_col[s0 * kStageCols]) >> 12 : 0;
-    keys[it] = (lb << 48) | ((cb < 0xFFFF ? cb : 0xFFFF) << 32) | uint64_t(it);
-    return;
-  }
-  keys[it] = (uint64_t(stage_col[s0 * kStageCols] / order_cols) << 32) | uint64_t(it);
+  const uint64_t lb = uint64_t(0xFFFF) - uint64_t(len / 32 < 0xFFFF ? len / 32 : 0xFFFF);
+  const uint64_t cb = len > 0 ? uint64_t(stage_col[s0 * kStageCols]) >> 12 : 0;
+  keys[it] = (lb << 48) | ((cb < 0xFFFF ? cb : 0xFFFF) << 32) | uint64_t(it);
 }
 
 __global__ void k_tg_item_place(int64_t items, const uint64_t* __restrict__ keys, const int32_t* __restrict__ tmp,
@@ -1338,12 +1349,12 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
   // pair).  Every wavefront leaves through the same test of b.
   int* next = reinterpret_cast<int*>(smem + kTicketOff);   // behind the pattern table
   int prev = -1;
-  // Which units a workgroup takes: the next of the launch order (one counter).  Diagnostic
-  // alternative (mode bit 256, see k_tg_item_keys for what it measured): the order dealt out in runs
-  // of 32 units (an XCD has 32 CUs), run r to XCD r mod 8, a workgroup taking the next unit of its
-  // own XCD's runs (one counter per XCD) and, when those are finished, of the other XCDs'.
+  // Which units a workgroup takes: the next of the launch order (one counter), or, for a plan
+  // ordered neighbours-together (see k_tg_item_keys), the order dealt out in runs of 32 units (an
+  // XCD has 32 CUs), a workgroup taking the next unit of its own XCD's runs (one counter per XCD)
+  // and, when those are finished, of the other XCDs'.  (Mode bits 256 / 1024 force it on / off.)
   const int xcd = int(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);   // XCC_ID
-  const bool by_xcd = (a.mode & 256) != 0;
+  const bool by_xcd = ((a.plan_counts[8] != 0) || (a.mode & 256)) && !(a.mode & 1024);
   int victim = 0;   // how many other XCDs' queues this workgroup has found empty
   for (;;) {
     int b = blockIdx.x;
@@ -1356,7 +1367,10 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
           while (victim < 8) {
             const int q = (xcd + victim) & 7;
             const int k = int(atomicAdd(&a.state->xcd_queue[q], 1u));
-            t = ((k >> 5) * 8 + q) * 32 + (k & 31);
+            // (rounds of eight runs go to the XCDs forwards and backwards in turn: the order is by
+            // falling length, and dealt one way only XCD 0 would get the longest run of every round)
+            const int round = k >> 5;
+            t = (round * 8 + ((round & 1) ? 7 - q : q)) * 32 + (k & 31);
             if (t < total) break;
             t = total;
             ++victim;
@@ -1594,7 +1608,7 @@ int sgnn_tilegroup_analyze(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
   const int rbits = ceil_log2(w.cap_runs + 1);
   if (5 + kSlotBits + rbits > 64) return fail(SGNN_ERR_INVALID, "key does not fit 64 bits");
   const unsigned T = 256;
-  HIP_TRY(hipMemsetAsync(w.counts, 0, 64, st));
+  HIP_TRY(hipMemsetAsync(w.counts, 0, 128, st));
   // rank the rows by degree (stable: ties keep row order)
   hipLaunchKernelGGL(k_tg_deg_keys, blocks_for(n_rows), dim3(T), 0, st, n_rows, rowptr, w.dkey_a, w.drow_a);
   HIP_TRY(hipGetLastError());
@@ -1670,7 +1684,7 @@ int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t sta
   TgPlan p = carve_tg_plan(plan, n_rows, stages, steps, items, long_groups);
   if (plan_bytes < p.total) return fail(SGNN_ERR_WORKSPACE, "tile-group plan buffer too small");
   const unsigned T = 256;
-  HIP_TRY(hipMemcpyAsync(p.counts, w.counts, 64, hipMemcpyDeviceToDevice, st));   // counts[7] = n_rows: the SpMM kernel checks its launch against them
+  HIP_TRY(hipMemcpyAsync(p.counts, w.counts, 128, hipMemcpyDeviceToDevice, st));   // counts[7] = n_rows: the SpMM kernel checks its launch against them
   hipLaunchKernelGGL(k_tg_grows, blocks_for(p.G * kRows), dim3(T), 0, st, n_rows, p.G * kRows, w.drow_b, p.grows);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_tg_copy_u32, blocks_for(p.G + 1), dim3(T), 0, st, p.G + 1, w.gstage0, p.gstage0, p.G + 1);
@@ -1692,7 +1706,7 @@ int sgnn_tilegroup_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t sta
                      w.lidx, w.itmp, w.cap_items, p.long_group, p.long_slot, p.long_nseg);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_tg_item_keys, blocks_for(items), dim3(T), 0, st, items, w.itmp, w.cap_items, p.stage_col,
-                     int(g_order_cols.load()), w.ikey_a);
+                     int(g_order_cols.load()), nnz, p.counts, w.ikey_a);
   HIP_TRY(hipGetLastError());
   size_t pb = w.prim_bytes;
   HIP_TRY(rocprim::radix_sort_keys(w.prim, pb, w.ikey_a, w.ikey_b, size_t(items), 0u, 64u, st));

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Work-item order and per-XCD work queues of the tile-group kernel, compared on one box
-(run on the GPU box):  python tools/xcd_probe.py [workload]
-order 0 = longest first (default); -1 = length buckets, then column block, then group.
-mode 0 = one work counter for the launch (default); 256 = one per XCD, runs of 32 neighbours."""
+"""Work-item order and per-XCD work queues of the tile-group kernel (run on the GPU box):
+    python tools/xcd_probe.py [workload]                 the library's choice and the three forced combinations, twice, timed
+    python tools/xcd_probe.py <workload> <order> <mode>   ten hops of one combination (for a counter pass)
+order 0 = chosen by the graph (default); 1 = longest first; -1 = neighbours together (length buckets,
+then column block, then group).
+mode 0 = work counters as the plan's order wants them (default); 256 = one per XCD, runs of 32
+neighbours; 1024 = one for the launch."""
 import os
 import sys
 
@@ -40,18 +43,24 @@ def run(reps=20):
     return e0.elapsed_time(e1) / reps, k_ms / max(k_n, 1)
 
 
+if len(sys.argv) > 3:
+    lib.sgnn_tune_set(b"tg_order", int(sys.argv[2]))
+    lib.sgnn_tune_set(b"tg_mode", int(sys.argv[3]))
+    hop, ker = run(10)
+    print(f"{wl} order {sys.argv[2]} mode {sys.argv[3]}: hop {hop:.3f} ms, main kernel {ker:.3f} ms", flush=True)
+    sys.exit(0)
 ref = None
 for rep in range(2):
-    for order in (0, -1):
+    for order, modes in ((0, (0,)), (1, (1024,)), (-1, (1024, 256))):
         lib.sgnn_tune_set(b"tg_order", order)
         adj._tg = None
-        for mode in (0, 256):
+        for mode in modes:
             lib.sgnn_tune_set(b"tg_mode", mode)
             Y = adj.propagate(X, 1)
             if ref is None:
                 ref = Y.clone()
             ok = bool(torch.equal(Y, ref))
             hop, ker = run()
-            print(f"{wl} order {order:2d} mode {mode:3d}: hop {hop:.3f} ms, main kernel {ker:.3f} ms, same bits as the first run: {ok}", flush=True)
+            print(f"{wl} order {order:2d} mode {mode:4d}: hop {hop:.3f} ms, main kernel {ker:.3f} ms, same bits as the first run: {ok}", flush=True)
 lib.sgnn_tune_set(b"tg_mode", 0)
 lib.sgnn_tune_set(b"tg_order", 0)
