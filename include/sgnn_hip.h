@@ -199,14 +199,16 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  * arithmetic, as enforced on the device: an element within 2^29 of its column's largest
  * magnitude is reproduced to 2^-22 relative, a smaller one to 2^-50 of that largest
  * magnitude; an operand with a non-finite element, an element of at least twice its
- * column's bound, or more than max(16, elements / 2^20) nonzero elements so far below their
- * column's largest magnitude (2^-33) that fewer than 17 of their bits survive, is refused:
+ * column's bound, or more than max(16, elements / 2^14) nonzero elements so far below their
+ * column's largest magnitude (2^-33) that fewer than 17 of their bits survive (the zero
+ * crossings of a continuous distribution leave about one in 10^6), is refused:
  * a device flag goes up, the matrix-core kernel does nothing, and the plain CSR kernel
  * launched behind it computes the result from the fp32 operand (bit-identical to
  * sgnn_spmm_csr_f32), with no host synchronisation.  Accepted operands give results as far
- * from the exact product as sgnn_spmm_csr_f32's plus at most 2^-21 of |A||X| per hop,
- * element by element (on ordinary data the two kernels agree to 2^-20 of |A||X|), and are
- * reproducible run to run.
+ * from the exact product as sgnn_spmm_csr_f32's plus at most 2^-21 of |A||X|, plus 2^-49 of
+ * the column's largest magnitude times the row's sum of weights, per hop, element by element
+ * (on ordinary data the two kernels agree to 2^-20 of |A||X|), and are reproducible run to
+ * run.
  *
  * Plan (once per matrix), two steps because its size depends on the matrix:
  *   sgnn_tilegroup_analyze  sorts and counts into `workspace`

@@ -30,7 +30,7 @@
 // differs from the vector kernels' by summation order and at most one extra rounding of
 // each input.  The split pass checks every element, counts the ones that keep fewer than
 // 17 of their bits (more than 2^33 below the largest) and raises a flag when X is not
-// finite or holds more than one such element per million; the SpMM kernel then does
+// finite or holds more than one such element in 2^14; the SpMM kernel then does
 // nothing and the fall-back launched behind it (the plain CSR kernel on the original
 // fp32 operand, guarded by the same flag) computes Y.
 //
@@ -59,6 +59,12 @@ constexpr int kSlotBits = 7;                     // log2(kStageCols)
 constexpr int kStepCols = 16;                    // K of one MFMA
 constexpr int kSlice = 128;                      // features of a slice (4 MFMA N-tiles)
 constexpr int kWaves = 8;
+#ifndef SGNN_TG_ISSUERS
+#define SGNN_TG_ISSUERS 8
+#endif
+constexpr int kIssuers = SGNN_TG_ISSUERS;        // wavefronts (the first of the workgroup) that issue a stage's DMA instructions
+constexpr int kIssuerRows = kStageCols / kIssuers;
+constexpr int kColRegs = kIssuerRows / 4, kRowInstr = 2 * kColRegs;
 constexpr int kEarlyRows = 2;                    // row DMA instructions of a wavefront issued ahead of the stage's first tile reads (4 and 8 measured 1 % slower)
 constexpr int kRing = 2;                         // stages resident in LDS: one being read, one arriving
 constexpr int kRowBytes = 512;                   // one node's slice: hi 256 B | lo 256 B
@@ -74,7 +80,7 @@ constexpr int kTicketOff = 496, kAmaxOff = 512;
 constexpr int kStageOutBytes = 16384;            // write-out staging per wavefront: 32 rows x 512 bytes
 constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;
 constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slack behind the step arrays (a stage's DMA over-reads)
-static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves, "a wavefront loads 16 rows of a stage");
+static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves && (kIssuers == 8 || kIssuers == 4), "a wavefront loads 16 (or 32) rows of a stage");
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
 static_assert(kTableBytes + kWaves * kStageOutBytes <= kLdsBytes, "the write-out staging must fit the ring");
 
@@ -709,11 +715,14 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
   if ((threadIdx.x & (kWave - 1)) == 0 && tiny) atomicAdd(&state->tiny, tiny);
 }
 
-// A continuous distribution leaves a handful of tiny elements among 10^8 (they change a sum
-// by less than 2^-50 of their feature's largest magnitude each); data with a genuinely wide
-// dynamic range inside a column has them by the thousand and goes to the fall-back kernel.
+// A continuous distribution leaves tiny elements where values cross zero: about one in 10^7 of
+// a Gaussian operand, one in 10^6 once two hops of averaging have pulled the bulk of a column
+// 2^10 below its largest entry (Reddit shape, 1.4 x 10^8 elements: 15 after one hop, 150 after
+// two).  Each changes a sum by less than 2^-50 of its feature's largest magnitude.  Data with a
+// genuinely wide dynamic range inside a column has them by the percent and goes to the
+// fall-back kernel: the limit is one element in 2^14.
 __host__ __device__ inline uint32_t tg_tiny_limit(int64_t elements) {
-  const int64_t lim = elements >> 20;
+  const int64_t lim = elements >> 14;
   return uint32_t(lim > 16 ? (lim < 0x7fffffff ? lim : 0x7fffffff) : 16);
 }
 
@@ -862,17 +871,17 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   // the stage has steps), the first-step table from this stage on, and the column ids of the
   // following stages, so that the next stage is issued from LDS and not from scalar loads
   // whose latency every wavefront would sit out once per stage.
-  auto issue_rows = [&](int s, const int (&col)[4], auto lo_tag, auto hi_tag) {   // row instructions lo .. hi - 1 of the wavefront's eight
+  auto issue_rows = [&](int s, const int (&col)[kColRegs], auto lo_tag, auto hi_tag) {   // row instructions lo .. hi - 1 of the wavefront's kRowInstr
     constexpr int lo = decltype(lo_tag)::value, hi = decltype(hi_tag)::value;
     const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
     // (lanes whose N-tile holds no feature below F fetch nothing: lane l moves segment l >> 4)
-    if (!(a.mode & 2) && (lane >> 4) < NT) {
+    if (!(a.mode & 2) && (lane >> 4) < NT && w < kIssuers) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < kRowInstr; ++i) {
         if (i < lo || i >= hi) continue;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(8 * w + i) * 1024u);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(kRowInstr * w + i) * 1024u);
         const uint32_t off = src_off + uint32_t(i & 1) * 256u;
-        const int c = (a.mode & 64) ? (col[i >> 1] & 4095) : col[i >> 1];   // diagnostics: every fetch an L2 hit
+        const int c = (a.mode & 64) ? (col[i >> 1] & ((a.mode & 512) ? 511 : 4095)) : col[i >> 1];   // diagnostics: every fetch from the first 4096 nodes' rows (10 MB at 602 features: the memory-side cache) or, with 512, the first 512 (1.3 MB: every XCD's L2)
         if (small) tg_dma16_off(xs, (uint32_t(c) << 9) | off, dst);
         else tg_dma16(xs + int64_t(c) * kRowBytes + off, dst);
       }
@@ -882,27 +891,45 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
     const int64_t sf = sf32;
     const uint32_t rec = buf + kStageRowsBytes;
-    if (w >= 6) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        if (((w - 6) * 2 + i) * 32 < steps)
-          tg_dma16(reinterpret_cast<const char*>(a.step_slots) + sf * 32 + ((w - 6) * 2 + i) * 1024 + lane * 16,
-                   __builtin_amdgcn_readfirstlane(rec + uint32_t((w - 6) * 2 + i) * 1024u));
-    } else if (w >= 1 && w <= 4) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        if (((w - 1) * 2 + i) * 16 < steps)
-          tg_dma16(reinterpret_cast<const char*>(a.step_bits) + sf * 64 + ((w - 1) * 2 + i) * 1024 + lane * 16,
-                   __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + uint32_t((w - 1) * 2 + i) * 1024u));
-    } else if (w == 5) {
+    auto slots_kb = [&](int i) {
+      if (i * 32 < steps)
+        tg_dma16(reinterpret_cast<const char*>(a.step_slots) + sf * 32 + i * 1024 + lane * 16,
+                 __builtin_amdgcn_readfirstlane(rec + uint32_t(i) * 1024u));
+    };
+    auto bits_kb = [&](int i) {
+      if (i * 16 < steps)
+        tg_dma16(reinterpret_cast<const char*>(a.step_bits) + sf * 64 + i * 1024 + lane * 16,
+                 __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + uint32_t(i) * 1024u));
+    };
+    auto first_steps = [&]() {
       tg_dma4(a.step0 + int64_t(s) * kSubs + lane, __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + kBitsBytes));
-    } else {
+    };
+    auto next_cols = [&]() {
       tg_dma16(a.stage_col + (int64_t(s) + 1) * kStageCols + lane * 4,
                __builtin_amdgcn_readfirstlane(rec + kSlotsBytes + kBitsBytes + kHdrBytes));
+    };
+    if (kIssuers == 8) {
+      if (w >= 6) {
+        slots_kb((w - 6) * 2);
+        slots_kb((w - 6) * 2 + 1);
+      } else if (w >= 1 && w <= 4) {
+        bits_kb((w - 1) * 2);
+        bits_kb((w - 1) * 2 + 1);
+      } else if (w == 5) {
+        first_steps();
+      } else {
+        next_cols();
+      }
+    } else if (w < kIssuers) {
+      if (w == 0) next_cols();
+      if (w == 1) first_steps();
+      slots_kb(w);
+      bits_kb(w);
+      bits_kb(w + 4);
     }
   };
-  auto issue = [&](int s, const int (&col)[4], int sf32, int steps) {
-    issue_rows(s, col, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+  auto issue = [&](int s, const int (&col)[kColRegs], int sf32, int steps) {
+    issue_rows(s, col, std::integral_constant<int, 0>{}, std::integral_constant<int, kRowInstr>{});
     issue_records(s, sf32, steps);
   };
 
@@ -926,9 +953,9 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   // stage can be asked for as soon as its barrier has fallen.
   int cur_sf = 0, cur_h0 = 0, cur_h1 = 0, cur_h2 = 0;
   if (ns > 0) {   // the item's first stage: ids and step counts from global memory
-    int col[4];
+    int col[kColRegs];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) col[b] = a.stage_col[int64_t(s0) * kStageCols + 16 * w + 4 * b + dma_row];
+    for (int b = 0; b < kColRegs; ++b) col[b] = a.stage_col[int64_t(s0) * kStageCols + kIssuerRows * (w & (kIssuers - 1)) + 4 * b + dma_row];
     const int32_t* st0 = a.step0 + int64_t(s0) * kSubs;
     cur_sf = __builtin_amdgcn_readfirstlane(st0[0]);
     cur_h0 = __builtin_amdgcn_readfirstlane(st0[2 * w]);
@@ -995,12 +1022,12 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     uint32_t ta, tb;
     h8 bh[NT], bl[NT];
     if (steps_on) record(offs, bt);
-    int col[4] = {0, 0, 0, 0};
+    int col[kColRegs] = {};
     int nsf = 0, nsf2 = 0, nh0 = 0, nh1 = 0, nh2 = 0;
     if (more) {
-      const int* nc = hdr + kHdrBytes / 4 + 16 * w + dma_row;
+      const int* nc = hdr + kHdrBytes / 4 + kIssuerRows * (w & (kIssuers - 1)) + dma_row;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) col[b] = nc[4 * b];
+      for (int b = 0; b < kColRegs; ++b) col[b] = nc[4 * b];
       nsf = hdr[kSubs];
       nsf2 = hdr[2 * kSubs];
       nh0 = hdr[kSubs + 2 * w];
@@ -1033,7 +1060,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     // issue between the steps, measured slower: the CU's memory pipeline takes ~1400 cycles
     // to accept a stage either way and the earlier it starts the earlier the rows arrive).
     if (more) {
-      issue_rows(s0 + k + 1, col, std::integral_constant<int, kEarlyRows>{}, std::integral_constant<int, 8>{});
+      issue_rows(s0 + k + 1, col, std::integral_constant<int, kEarlyRows>{}, std::integral_constant<int, kRowInstr>{});
       issue_records(s0 + k + 1, nsf, nsf2 - nsf);
       cur_sf = nsf;
       cur_h0 = nh0;
@@ -1136,146 +1163,176 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
                : "=&v"(row_v), "=&v"(dr_v), "=&v"(cr_v)
                : "v"(my_row), "v"(__builtin_bit_cast(int, my_dr)), "v"(__builtin_bit_cast(int, my_cr)));
-  auto pick = [&](int x, int src) {   // lane src (h = 0) or src + 4 (h = 1) of x; src is a constant
-    const int lo = __builtin_amdgcn_readlane(x, src), hi = __builtin_amdgcn_readlane(x, src + 4);
-    return h ? hi : lo;
-  };
   if (a.mode & 32) return;   // diagnostics: nothing written
-  const bool to_planes = out < 0 && a.planes_out != nullptr;   // uniform
-  // The bounds of this lane's features (one per N-tile): the power of two the accumulators are
-  // scaled back by, and the scale of the operand written for the next hop.  A row of
-  // D^-1 (A + I) sums to one, so no element of that operand exceeds the largest of the operand
-  // read here: that measured maximum (or, where ranks would have to agree on it first, the
-  // older bound) is the next operand's bound.
-  float inv_sc[NT], sc_out[NT];
-  uint32_t mx[NT], nxt_b[NT];
+  const bool fin = out < 0;                                  // uniform: finished rows (else raw partial sums)
+  const bool to_planes = fin && a.planes_out != nullptr;     // uniform
+  const bool diag = DIAG && fin;                             // uniform (DIAG: the launch has a diagonal correction)
+  const bool add = fin && a.addend != nullptr;               // uniform
+  // Two passes per sub-tile.  The accumulators go to LDS as they are; the rows are then taken
+  // back 16 bytes per lane -- lane l holds features 4 (l & 31) .. + 3 of row 2 j + (l >> 5) -- and
+  // everything a finished row needs is done in that layout: the scale back, the other column
+  // block's raw sums and the row's own operand elements for the diagonal correction (read as
+  // whole 512-byte row pieces, all eight row pairs of a batch asked for before the first is
+  // used, the next batch before this one is worked on: done in the accumulators' layout these
+  // loads came to eight round trips to memory per wavefront and unit of work, a twentieth of
+  // a unit's time), the row scaling, the split into the next operand's planes.
+  const int c = lane & 31;                     // which 16 bytes of a staged row
+  const int f0 = slice * kSlice + 4 * c;       // the lane's first feature
+  const bool live = (c >> 3) < NT;             // N-tiles this unit did not compute hold nothing
+  // The bounds of this lane's features: the power of two the accumulators are scaled back by,
+  // and the scale of the operand written for the next hop.  A row of D^-1 (A + I) sums to one,
+  // so no element of that operand exceeds the largest of the operand read here: that measured
+  // maximum (or, where ranks would have to agree on it first, the older bound) is the next
+  // operand's bound.
+  float inv4[4], sc4[4];
+  uint32_t nxt4[4];
+  u32x4 mx4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int f = slice * kSlice + nt * 32 + (lane & 31);
-    const uint32_t bnd = bound_of(a.state, a.Fpad)[f];
-    const uint32_t nxt = (to_planes && a.adapt) ? a.state->amax[f] : bnd;
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t bnd = bound_of(a.state, a.Fpad)[f0 + i];
+    const uint32_t nxt = (to_planes && a.adapt) ? a.state->amax[f0 + i] : bnd;
     const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
-    inv_sc[nt] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);   // 1 / scale, exact: a power of two
-    sc_out[nt] = tg_scale(nxt);
-    nxt_b[nt] = nxt;
-    mx[nt] = 0;
+    inv4[i] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);   // 1 / scale, exact: a power of two
+    sc4[i] = tg_scale(nxt);
+    nxt4[i] = nxt;
   }
   uint32_t tiny = 0;
   __builtin_amdgcn_s_barrier();   // the ring is no longer read
   const uint32_t stg = uint32_t(kTableBytes) + uint32_t(w) * uint32_t(kStageOutBytes);
+  const bool whole = int64_t(slice + 1) * kSlice <= a.F;   // every feature of the slice exists
   const bool y4 = (a.ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 16 == 0);
   const bool y2 = (a.ldy % 2 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 8 == 0);
+  const bool x4 = whole && (a.ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(a.X) % 16 == 0);
+  const bool x2 = whole && (a.ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(a.X) % 8 == 0);
+  const bool d4 = whole && (a.ld_addend % 4 == 0) && (reinterpret_cast<uintptr_t>(a.addend) % 16 == 0);
+  const bool d2 = whole && (a.ld_addend % 2 == 0) && (reinterpret_cast<uintptr_t>(a.addend) % 8 == 0);
+  // four floats of a row from feature f0 on, in the widest pieces the row's alignment allows; in
+  // a slice that F cuts short, feature by feature (one past F reads the last: the value is not used)
+  auto load4 = [&](const float* rowp, bool v4, bool v2) -> f32x4 {
+    if (v4) return *reinterpret_cast<const f32x4*>(rowp + f0);
+    if (v2) {
+      const f32x2 p0 = *reinterpret_cast<const f32x2*>(rowp + f0), p1 = *reinterpret_cast<const f32x2*>(rowp + f0 + 2);
+      return f32x4{p0[0], p0[1], p1[0], p1[1]};
+    }
+    f32x4 r;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const bool diag = DIAG && out < 0;   // uniform (DIAG: the launch has a diagonal correction)
-    const bool add = out < 0 && a.addend != nullptr;   // uniform
-    // four accumulator registers (eight rows of the sub-tile) at a time: what they need from
-    // memory -- the other column block's raw sums, the rows' own operand elements for the diagonal
-    // correction -- is asked for in one go and without a branch around any load (a row that does
-    // not exist reads row 0, a feature past F reads the last one; neither value is used), so that
-    // one wait covers it.
+    for (int i = 0; i < 4; ++i) r[i] = rowp[min(f0 + i, int(a.F) - 1)];
+    return r;
+  };
+  struct HalfRows { hv4 hi, lo; };
+  auto lane_row = [&](int x, int tt, int j) {   // element 2 j (h = 0) or 2 j + 1 (h = 1) of the sub-tile's 32 in x
+    const int lo = __builtin_amdgcn_readlane(x, kSub * tt + 2 * j), hi = __builtin_amdgcn_readlane(x, kSub * tt + 2 * j + 1);
+    return h ? hi : lo;
+  };
+  constexpr int kBatch = 8;   // row pairs whose loads are in flight together
+  auto fetch = [&](int tt, int b, f32x4 (&xq)[kBatch], f32x4 (&aq)[kBatch]) {
 #pragma unroll
-    for (int v0 = 0; v0 < 16; v0 += 4) {
-      [[maybe_unused]] float xq[4][NT], aq[4][NT];
+    for (int jj = 0; jj < kBatch; ++jj) {
+      const int row = max(lane_row(row_v, tt, b * kBatch + jj), 0);   // a row that does not exist reads row 0
       if constexpr (DIAG) if (diag) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int v = v0 + i;
-          const int64_t node = a.x_row_offset + max(pick(row_v, kSub * tt + (v & 3) + 8 * (v >> 2)), 0);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            if (a.X != nullptr) {
-              xq[i][nt] = a.X[node * a.ldx + min(slice * kSlice + nt * 32 + (lane & 31), a.F - 1)];
-            } else {   // the operand exists only as planes: hi + lo / 2048, scaled back
-              const char* pr = xs + node * kRowBytes + (nt * 32 + (lane & 31)) * 2;
-              const float hv = float(*reinterpret_cast<const _Float16*>(pr));
-              const float lv = float(*reinterpret_cast<const _Float16*>(pr + kRowBytes / 2));
-              xq[i][nt] = (hv + lv * (1.0f / 2048.0f)) * inv_sc[nt];
-            }
-          }
+        const int64_t node = a.x_row_offset + row;
+        if (a.X != nullptr) {
+          xq[jj] = load4(a.X + node * a.ldx, x4, x2);
+        } else {   // the operand exists only as planes
+          const char* pr = xs + node * kRowBytes + c * 8;
+          xq[jj] = __builtin_bit_cast(f32x4, HalfRows{*reinterpret_cast<const hv4*>(pr), *reinterpret_cast<const hv4*>(pr + kRowBytes / 2)});
         }
       }
-      if (add) {
+      if (add) aq[jj] = load4(a.addend + int64_t(row) * a.ld_addend, d4, d2);
+    }
+  };
+  auto stage_out = [&](auto tt_tag) {   // accumulator register v of a lane: row (v & 3) + 8 (v >> 2) + 4 h, feature lane & 31 of the N-tile
+    constexpr int TT = decltype(tt_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int v = v0 + i;
-          const int row = max(pick(row_v, kSub * tt + (v & 3) + 8 * (v >> 2)), 0);
+    for (int v = 0; v < 16; ++v) {
+      const uint32_t rl = uint32_t((v & 3) + 8 * (v >> 2) + 4 * h);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            aq[i][nt] = a.addend[int64_t(row) * a.ld_addend + min(slice * kSlice + nt * 32 + (lane & 31), a.F - 1)];
-        }
-      }
+      for (int nt = 0; nt < NT; ++nt)
+        *lds<float>(stg + rl * uint32_t(kRowBytes) + uint32_t(nt * 32 + (lane & 31)) * 4u) = acc[TT][nt][v];
+    }
+  };
+  auto finish = [&](int tt, int b, const f32x4 (&xq)[kBatch], const f32x4 (&aq)[kBatch]) {
+#pragma unroll
+    for (int jj = 0; jj < kBatch; ++jj) {
+      const int j = b * kBatch + jj;
+      const int row = lane_row(row_v, tt, j);
+      const float dr = __builtin_bit_cast(float, lane_row(dr_v, tt, j));
+      const float cr = __builtin_bit_cast(float, lane_row(cr_v, tt, j));
+      const f32x4 q4 = *lds<const f32x4>(stg + uint32_t(j) * 1024u + uint32_t(lane) * 16u);
+      f32x4 y4v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int v = v0 + i;
-        const int src = kSub * tt + (v & 3) + 8 * (v >> 2);
-        const uint32_t rl = uint32_t((v & 3) + 8 * (v >> 2) + 4 * h);   // row inside the sub-tile
-        const int row = pick(row_v, src);
-        const float dr = __builtin_bit_cast(float, pick(dr_v, src));
-        const float cr = __builtin_bit_cast(float, pick(cr_v, src));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const uint32_t fl = uint32_t(nt * 32 + (lane & 31));   // feature inside the slice
-          float y = acc[tt][nt][v] * inv_sc[nt];   // exact: a power of two
-          if (out < 0) {
-            if (add) y += aq[i][nt];
-            if constexpr (DIAG) y = fmaf(a.w_off, y, cr * xq[i][nt]);
-            else if (a.w_off != 1.0f) y *= a.w_off;
-            if (a.dinv_row != nullptr) {
-              y = y * dr;
-              if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
+        float y = q4[i] * inv4[i];   // exact: a power of two
+        if (fin) {
+          if (add) y += aq[jj][i];
+          if constexpr (DIAG) {
+            float xv;
+            if (a.X != nullptr) {
+              xv = xq[jj][i];
+            } else {   // hi + lo / 2048, scaled back
+              const HalfRows hr = __builtin_bit_cast(HalfRows, xq[jj]);
+              xv = (float(hr.hi[i]) + float(hr.lo[i]) * (1.0f / 2048.0f)) * inv4[i];
             }
-            // rows that do not exist, and features past F (the correction read a clamped feature
-            // for them): zero, as the planes' padding must be
-            if (row < 0 || slice * kSlice + int(fl) >= a.F) y = 0.0f;
+            y = fmaf(a.w_off, y, cr * xv);
+          } else if (a.w_off != 1.0f) {
+            y *= a.w_off;
           }
-          if (to_planes) {
-            _Float16 hv, lv;
-            tg_split_one(y, sc_out[nt], hv, lv, tiny);
-            const uint32_t yb = __builtin_bit_cast(uint32_t, y) & 0x7FFFFFFFu;
-            mx[nt] = yb > mx[nt] ? yb : mx[nt];
-            *lds<_Float16>(stg + rl * uint32_t(kRowBytes) + fl * 2u) = hv;
-            *lds<_Float16>(stg + rl * uint32_t(kRowBytes) + uint32_t(kRowBytes / 2) + fl * 2u) = lv;
-          } else {
-            *lds<float>(stg + rl * uint32_t(kRowBytes) + fl * 4u) = y;
+          if (a.dinv_row != nullptr) {
+            y = y * dr;
+            if (a.epilogue == SGNN_EPI_SCALE_ROW2) y = y * dr;
           }
+          // rows that do not exist, features past F and N-tiles not computed: zero, as the planes' padding must be
+          if (row < 0 || f0 + i >= a.F || !live) y = 0.0f;
         }
+        y4v[i] = y;
       }
-    }
-    // the staged rows leave 16 bytes per lane: instruction j carries rows 2 j and 2 j + 1
-#pragma unroll 4
-    for (int j = 0; j < 16; ++j) {
-      const int lo_row = __builtin_amdgcn_readlane(row_v, kSub * tt + 2 * j);
-      const int hi_row = __builtin_amdgcn_readlane(row_v, kSub * tt + 2 * j + 1);
-      const int row = h ? hi_row : lo_row;
-      const f32x4 q4 = *lds<const f32x4>(stg + uint32_t(j) * 1024u + uint32_t(lane) * 16u);
-      const int c = lane & 31;   // which 16 bytes of the row
       if (to_planes) {
+        hv4 hq, lq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          _Float16 hv, lv;
+          const float yv = y4v[i];   // (a copy: __builtin_bit_cast of a vector element reads element 0)
+          tg_split_one(yv, sc4[i], hv, lv, tiny);
+          const uint32_t yb = __builtin_bit_cast(uint32_t, yv) & 0x7FFFFFFFu;
+          mx4[i] = yb > mx4[i] ? yb : mx4[i];
+          hq[i] = hv;
+          lq[i] = lv;
+        }
         if (row < 0) continue;
-        // chunks 0..15: hi plane, 8 features each; 16..31: lo plane.  N-tiles this unit did not compute hold zeros.
-        const bool live = ((c & 15) >> 2) < NT;
-        const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        *reinterpret_cast<f32x4*>(a.planes_out + int64_t(slice) * a.slice_bytes_out + (a.out_row_offset + row) * kRowBytes + c * 16) =
-            live ? q4 : z4;
-      } else if (out < 0) {
+        char* dst = a.planes_out + int64_t(slice) * a.slice_bytes_out + (a.out_row_offset + row) * kRowBytes + c * 8;
+        *reinterpret_cast<hv4*>(dst) = hq;
+        *reinterpret_cast<hv4*>(dst + kRowBytes / 2) = lq;
+      } else if (fin) {
         if (row < 0) continue;
-        const int f = slice * kSlice + 4 * c;
-        float* dst = a.Y + int64_t(row) * a.ldy + f;
-        if (f + 4 <= a.F && y4) {
-          *reinterpret_cast<f32x4*>(dst) = q4;
-        } else if (f + 4 <= a.F && y2) {
-          *reinterpret_cast<f32x2*>(dst) = f32x2{q4[0], q4[1]};
-          *reinterpret_cast<f32x2*>(dst + 2) = f32x2{q4[2], q4[3]};
+        float* dst = a.Y + int64_t(row) * a.ldy + f0;
+        if (f0 + 4 <= a.F && y4) {
+          *reinterpret_cast<f32x4*>(dst) = y4v;
+        } else if (f0 + 4 <= a.F && y2) {
+          *reinterpret_cast<f32x2*>(dst) = f32x2{y4v[0], y4v[1]};
+          *reinterpret_cast<f32x2*>(dst + 2) = f32x2{y4v[2], y4v[3]};
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (f + i < a.F) dst[i] = q4[i];
+            if (f0 + i < a.F) dst[i] = y4v[i];
         }
       } else {
         const int rr = 2 * kSub * w + kSub * tt + 2 * j + h;
-        *reinterpret_cast<f32x4*>(a.partial + (int64_t(out) * kRows + rr) * a.Fpad + slice * kSlice + 4 * c) = q4;
+        *reinterpret_cast<f32x4*>(a.partial + (int64_t(out) * kRows + rr) * a.Fpad + slice * kSlice + 4 * c) = y4v;
       }
     }
+  };
+  {
+    [[maybe_unused]] f32x4 xa[kBatch], xb[kBatch], aa[kBatch], ab[kBatch];
+    fetch(0, 0, xa, aa);
+    stage_out(std::integral_constant<int, 0>{});
+    fetch(0, 1, xb, ab);
+    finish(0, 0, xa, aa);
+    fetch(1, 0, xa, aa);
+    finish(0, 1, xb, ab);
+    stage_out(std::integral_constant<int, 1>{});
+    fetch(1, 1, xb, ab);
+    finish(1, 0, xa, aa);
+    finish(1, 1, xb, ab);
   }
   if (to_planes) {
     // what the next hop needs to know about the operand just written: whether the planes hold
@@ -1284,17 +1341,17 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
     bool bad = false;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bad |= tg_beyond(mx[nt], nxt_b[nt]);
+    for (int i = 0; i < 4; ++i) bad |= tg_beyond(mx4[i], nxt4[i]);
     const bool any_bad = __any(bad);
     if (lane == 0) {
       if (tiny) atomicAdd(&a.state_out->tiny, tiny);
       if (any_bad) atomicOr(&a.state_out->flag, 1u);
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const uint32_t o = uint32_t(__shfl_xor(int(mx[nt]), 32));
-      const uint32_t m = o > mx[nt] ? o : mx[nt];
-      if (h == 0 && m) atomicMax(reinterpret_cast<uint32_t*>(smem + kAmaxOff) + (nt * 32 + lane), m);
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t o = uint32_t(__shfl_xor(int(mx4[i]), 32));
+      const uint32_t m = o > mx4[i] ? o : mx4[i];
+      if (h == 0 && m) atomicMax(reinterpret_cast<uint32_t*>(smem + kAmaxOff) + (4 * c + i), m);
     }
     __syncthreads();
     if (tid < kSlice) {

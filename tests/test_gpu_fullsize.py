@@ -79,6 +79,13 @@ def test_reddit_shape_full_size_properties(gpu_device):
     chain = adj.propagate(X, 2)
     hops = adj.propagate(Y_rg, 1)
     assert float((chain - hops).norm() / hops.norm()) <= TOL
+    # three hops: the operands of the later hops hold a hundred-odd elements at zero crossings that
+    # the planes keep only to 2^-50 of their column's largest magnitude; that is no reason to leave
+    # the matrix cores (the flag words of all three operands stay 0)
+    chain3 = adj.propagate(X, 3)
+    assert adj._tg_bufs[F]["states"][:3, 1].tolist() == [0, 0, 0]
+    hops3 = adj.propagate(hops, 1)
+    assert float((chain3 - hops3).norm() / hops3.norm()) <= TOL
 
 
 def test_reddit_shape_weight2_full_size_three_kernels_agree(gpu_device):

@@ -36,4 +36,17 @@ for _ in range(40):
 e1.record()
 torch.cuda.synchronize()
 k_ms, k_n = _lib.kernel_time_ms()
-print(sys.argv[1], "hop %.3f ms, main kernel %.3f ms" % (e0.elapsed_time(e1) / 40, k_ms / k_n), flush=True)
+for K in [int(v) for v in os.environ.get("AB_K", "").split(",") if v]:
+    adj.propagate(X, K)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        adj.propagate(X, K)
+    e1.record()
+    torch.cuda.synchronize()
+    print(sys.argv[1], "K = %d: %.3f ms, flags %s" % (K, e0.elapsed_time(e1) / 5, adj._tg_bufs[F]["states"][:, :8].tolist()), flush=True)
+Y = adj.propagate(X, 1)
+adj.use_tilegroup = False
+Yr = adj.propagate(X, 1)
+print(sys.argv[1], "hop %.3f ms, main kernel %.3f ms, normwise difference from the row-group kernel %.2e"
+      % (e0.elapsed_time(e1) / 40, k_ms / k_n, float((Y - Yr).norm() / Yr.norm())), flush=True)

@@ -109,7 +109,7 @@ if os.environ.get("TG_MODES"):
     adj.use_tilegroup = True
     for m in [int(v) for v in os.environ["TG_MODES"].split(",")]:
         _lib.load().sgnn_tune_set(b"tg_mode", m)
-        print(f"mode {m} (1 = no steps, 2 = no row DMA, 32 = no rows written, 64 = all fetches L2 hits): {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
+        print(f"mode {m} (1 = no steps, 2 = no row DMA, 32 = no rows written, 64 = all fetches from the first 4096 rows, 576 = from the first 512): {timeit(lambda: adj.propagate(X, 1)):.3f} ms/hop", flush=True)
 print(f"tile-group {t_tg:.3f} ms/hop   row-group {t_rg:.3f} ms/hop   normwise diff {err:.2e}  element-wise {el:.2e}", flush=True)
 if os.environ.get("TG_SWEEP"):
     adj.use_tilegroup = True
