@@ -78,11 +78,12 @@ constexpr int kStageBytes = kStageRowsBytes + kSlotsBytes + kBitsBytes + kHdrByt
 constexpr int kTableBytes = 1024;                // LDS offset 0: pattern table (16 entries of 8 bytes), the work ticket at 496, at 512 the 128 per-feature maxima of a unit's written operand; the stage buffers follow
 constexpr int kTicketOff = 496, kAmaxOff = 512;
 constexpr int kStageOutBytes = 16384;            // write-out staging per wavefront: 32 rows x 512 bytes
+constexpr int kRowTabBytes = 768;                // write-out: a wavefront's 64 row ids, row scales and diagonal factors, behind the staging areas
 constexpr int kLdsBytes = kTableBytes + kRing * kStageBytes;
 constexpr int kPadSteps = 2 * kMaxStageSteps;                   // readable slack behind the step arrays (a stage's DMA over-reads)
 static_assert((1 << kSlotBits) == kStageCols && kStageCols == 16 * kWaves && (kIssuers == 8 || kIssuers == 4), "a wavefront loads 16 (or 32) rows of a stage");
 static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned stage buffers");
-static_assert(kTableBytes + kWaves * kStageOutBytes <= kLdsBytes, "the write-out staging must fit the ring");
+static_assert(kTableBytes + kWaves * (kStageOutBytes + kRowTabBytes) <= kLdsBytes, "the write-out staging must fit the ring");
 
 std::atomic<int> g_seg_stages{0};     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
 std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_order", v)): 0 = chosen by the graph; 1 = longest first; < 0 = neighbours together (length buckets, then column block, then group); > 1 = by column blocks of this width
@@ -1154,15 +1155,10 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   // is free once every wavefront has left the stage loop -- and leave as whole 512-byte rows,
   // 16 bytes per lane.  Each wavefront stages its own 32 rows of a sub-tile, so nothing but the
   // one barrier in front is needed (a wavefront's LDS accesses execute in order).
-  // The wavefront's 64 rows and their scales, looked up once per lane before the stage loop,
-  // are handed out by v_readlane.  They came from memory; copied once through a register move
-  // they are plain register values (otherwise the compiler, unable to prove across the branches
-  // of the unrolled write-out that the loads have landed, waits for ALL outstanding memory
-  // operations, the stores of the row before included, in front of every row).
-  int row_v, dr_v, cr_v;
-  asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
-               : "=&v"(row_v), "=&v"(dr_v), "=&v"(cr_v)
-               : "v"(my_row), "v"(__builtin_bit_cast(int, my_dr)), "v"(__builtin_bit_cast(int, my_cr)));
+  // The wavefront's 64 rows and their scales, looked up once per lane before the stage loop, go
+  // to a small table in LDS behind the staging areas (written after the barrier below); a lane of
+  // the row-major pass reads the entry of the row it carries.  (Handed out by v_readlane they
+  // took 200 scalar registers, which the compiler spilled.)
   if (a.mode & 32) return;   // diagnostics: nothing written
   const bool fin = out < 0;                                  // uniform: finished rows (else raw partial sums)
   const bool to_planes = fin && a.planes_out != nullptr;     // uniform
@@ -1198,7 +1194,12 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   }
   uint32_t tiny = 0;
   __builtin_amdgcn_s_barrier();   // the ring is no longer read
+  const unsigned long long wall_bar = dbg ? wall_clock64() : 0;
   const uint32_t stg = uint32_t(kTableBytes) + uint32_t(w) * uint32_t(kStageOutBytes);
+  const uint32_t rows_tab = uint32_t(kTableBytes + kWaves * kStageOutBytes) + uint32_t(w) * uint32_t(kRowTabBytes);
+  *lds<int>(rows_tab + uint32_t(lane) * 4u) = my_row;
+  *lds<float>(rows_tab + 256u + uint32_t(lane) * 4u) = my_dr;
+  *lds<float>(rows_tab + 512u + uint32_t(lane) * 4u) = my_cr;
   const bool whole = int64_t(slice + 1) * kSlice <= a.F;   // every feature of the slice exists
   const bool y4 = (a.ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 16 == 0);
   const bool y2 = (a.ldy % 2 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 8 == 0);
@@ -1220,15 +1221,18 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     return r;
   };
   struct HalfRows { hv4 hi, lo; };
-  auto lane_row = [&](int x, int tt, int j) {   // element 2 j (h = 0) or 2 j + 1 (h = 1) of the sub-tile's 32 in x
-    const int lo = __builtin_amdgcn_readlane(x, kSub * tt + 2 * j), hi = __builtin_amdgcn_readlane(x, kSub * tt + 2 * j + 1);
-    return h ? hi : lo;
-  };
-  constexpr int kBatch = 8;   // row pairs whose loads are in flight together
+  const uint32_t my_tab = rows_tab + uint32_t(h) * 4u;   // entry 2 j + h of a sub-tile: the row this lane carries in row pair j
+  auto lane_row = [&](int tt, int j) { return *lds<const int>(my_tab + uint32_t(kSub * tt + 2 * j) * 4u); };
+  constexpr int kBatch = 4;   // row pairs whose loads are in flight together
   auto fetch = [&](int tt, int b, f32x4 (&xq)[kBatch], f32x4 (&aq)[kBatch]) {
 #pragma unroll
     for (int jj = 0; jj < kBatch; ++jj) {
-      const int row = max(lane_row(row_v, tt, b * kBatch + jj), 0);   // a row that does not exist reads row 0
+      const int row = max(lane_row(tt, b * kBatch + jj), 0);   // a row that does not exist reads row 0
+      if (a.mode & 2048) {   // diagnostics: nothing read for the write-out (results wrong)
+        xq[jj] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        aq[jj] = xq[jj];
+        continue;
+      }
       if constexpr (DIAG) if (diag) {
         const int64_t node = a.x_row_offset + row;
         if (a.X != nullptr) {
@@ -1255,9 +1259,9 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
 #pragma unroll
     for (int jj = 0; jj < kBatch; ++jj) {
       const int j = b * kBatch + jj;
-      const int row = lane_row(row_v, tt, j);
-      const float dr = __builtin_bit_cast(float, lane_row(dr_v, tt, j));
-      const float cr = __builtin_bit_cast(float, lane_row(cr_v, tt, j));
+      const int row = lane_row(tt, j);
+      const float dr = *lds<const float>(my_tab + 256u + uint32_t(kSub * tt + 2 * j) * 4u);
+      const float cr = *lds<const float>(my_tab + 512u + uint32_t(kSub * tt + 2 * j) * 4u);
       const f32x4 q4 = *lds<const f32x4>(stg + uint32_t(j) * 1024u + uint32_t(lane) * 16u);
       f32x4 y4v;
 #pragma unroll
@@ -1303,14 +1307,34 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
         *reinterpret_cast<hv4*>(dst) = hq;
         *reinterpret_cast<hv4*>(dst + kRowBytes / 2) = lq;
       } else if (fin) {
-        if (row < 0) continue;
-        float* dst = a.Y + int64_t(row) * a.ldy + f0;
-        if (f0 + 4 <= a.F && y4) {
-          *reinterpret_cast<f32x4*>(dst) = y4v;
-        } else if (f0 + 4 <= a.F && y2) {
-          *reinterpret_cast<f32x2*>(dst) = f32x2{y4v[0], y4v[1]};
-          *reinterpret_cast<f32x2*>(dst + 2) = f32x2{y4v[2], y4v[3]};
+        float* dst = a.Y + int64_t(max(row, 0)) * a.ldy + f0;
+        if (y4) {
+          if (row < 0) continue;
+          if (f0 + 4 <= a.F) {
+            *reinterpret_cast<f32x4*>(dst) = y4v;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (f0 + i < a.F) dst[i] = y4v[i];
+          }
+        } else if (y2) {
+          // Rows aligned to 8 bytes only (F = 602): stored as they lie, 8 bytes per lane at a
+          // stride of 16, every 32-byte sector of Y would be written in two halves by two
+          // instructions.  The finished row goes back to its staging area and is taken up again
+          // as two runs of 256 contiguous bytes: lane c carries features 2 c, 2 c + 1 and
+          // 64 + 2 c, 65 + 2 c.
+          const uint32_t back = stg + uint32_t(j) * 1024u + uint32_t(h) * 512u;
+          *lds<f32x4>(back + uint32_t(c) * 16u) = y4v;
+          const f32x2 pa = *lds<const f32x2>(back + uint32_t(c) * 8u), pb = *lds<const f32x2>(back + 256u + uint32_t(c) * 8u);
+          if (row < 0) continue;
+          float* d2 = a.Y + int64_t(row) * a.ldy + slice * kSlice + 2 * c;
+          const int fa = slice * kSlice + 2 * c, fb = fa + 64;
+          if (fa + 2 <= a.F) *reinterpret_cast<f32x2*>(d2) = pa;
+          else if (fa < a.F) d2[0] = pa[0];
+          if (fb + 2 <= a.F) *reinterpret_cast<f32x2*>(d2 + 64) = pb;
+          else if (fb < a.F) d2[64] = pb[0];
         } else {
+          if (row < 0) continue;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (f0 + i < a.F) dst[i] = y4v[i];
@@ -1323,16 +1347,24 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   };
   {
     [[maybe_unused]] f32x4 xa[kBatch], xb[kBatch], aa[kBatch], ab[kBatch];
+    constexpr int kBatches = 16 / kBatch;   // per sub-tile
     fetch(0, 0, xa, aa);
     stage_out(std::integral_constant<int, 0>{});
-    fetch(0, 1, xb, ab);
-    finish(0, 0, xa, aa);
-    fetch(1, 0, xa, aa);
-    finish(0, 1, xb, ab);
-    stage_out(std::integral_constant<int, 1>{});
-    fetch(1, 1, xb, ab);
-    finish(1, 0, xa, aa);
-    finish(1, 1, xb, ab);
+#pragma unroll
+    for (int b = 0; b < 2 * kBatches; ++b) {   // batch b of the two sub-tiles' 2 * kBatches; the next batch's loads go out first
+      const int tt = b / kBatches, bb = b % kBatches;
+      if (b + 1 < 2 * kBatches) {
+        if (b % 2 == 0) fetch((b + 1) / kBatches, (b + 1) % kBatches, xb, ab);
+        else fetch((b + 1) / kBatches, (b + 1) % kBatches, xa, aa);
+      }
+      if (b == kBatches) stage_out(std::integral_constant<int, 1>{});
+      if (b % 2 == 0) finish(tt, bb, xa, aa);
+      else finish(tt, bb, xb, ab);
+      if (b == 0 && dbg && lane == 0 && w == 0 && work < kDbgSpans) {   // since the end of the stage loop: the barrier, the first batch stored (100 MHz ticks)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_tg_span[8 * work + 7] = ((wall_clock64() - wall_begin) << 32) | ((wall_bar - wall_begin) & 0xFFFFFFFFull);
+      }
+    }
   }
   if (to_planes) {
     // what the next hop needs to know about the operand just written: whether the planes hold

@@ -86,6 +86,10 @@ if os.environ.get("TG_CYCLES"):
               f"stage loop {np.median(sp[:, 1] - sp[:, 0]) * 1e-2:.1f} / {(sp[:, 1] - sp[:, 0]).mean() * 1e-2:.1f}; "
               f"wavefront 0 writing its rows {np.median(sp[:, 4] - sp[:, 1]) * 1e-2:.1f} / {(sp[:, 4] - sp[:, 1]).mean() * 1e-2:.1f}; "
               f"until the workgroup has its next unit {np.median((sp[:, 6] - sp[:, 4])[ok]) * 1e-2:.1f} / {(sp[:, 6] - sp[:, 4])[ok].mean() * 1e-2:.1f}")
+        bar = (sp[:, 7] & 0xFFFFFFFF) - (sp[:, 1] - sp[:, 0])
+        first = (sp[:, 7] >> 32) - (sp[:, 1] - sp[:, 0])
+        print(f"  of the write-out, us after wavefront 0 left the stage loop (median / mean): barrier passed {np.median(bar) * 1e-2:.1f} / {bar.mean() * 1e-2:.1f}; "
+              f"first eight row pairs stored and acknowledged {np.median(first) * 1e-2:.1f} / {first.mean() * 1e-2:.1f}")
         dur = (sp[:, 1] - sp[:, 0]) * 1e-2
         gaps, busy_by_xcc, end_by_xcc = [], {}, {}
         for cu in np.unique(sp[:, 2]):
