@@ -563,9 +563,12 @@ def main():
             extra["exchange_bytes_per_rank_per_hop"] = (
                 (padj.max_rows * padj.world if padj.halo is None else padj.halo["n_recv"]) * ((Fr + 127) // 128 * 128) * 4)
             kernel_path = ("tile-group SpMM on the rank's own-columns and remote-columns blocks; every rank splits only "
-                           "its own rows and fp16 planes travel, one exchange per 128-feature slice")
-            kernels_in_step = ("k_tg_amax + all_reduce(max) + k_tg_split (own rows) + exchange || k_tg_spmm (own columns) "
-                               "+ k_tg_spmm (remote columns, adds the own-columns sums) + k_tg_combine")
+                           "its own rows and fp16 planes travel, one exchange per 128-feature slice; the remote-columns "
+                           f"block is multiplied in units of {padj.slices_per_exchange} slice(s) as they land")
+            kernels_in_step = ("k_tg_amax + all_reduce(max) + k_tg_split (own rows) + exchange || [k_tg_spmm (own columns) "
+                               "+ per unit of slices: k_tg_spmm (remote columns, adds the own-columns sums) + k_tg_combine]")
+            extra["exchange_unit_slices"] = padj.slices_per_exchange
+            extra["reserved_cus_beside_exchange"] = padj._reserved_cus()
             main_kernel = "k_tg_spmm"
         else:
             blk = padj.remote if (padj.last_schedule == "local-block" and padj.remote is not None) else local

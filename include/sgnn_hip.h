@@ -262,6 +262,18 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           item, feature slice) pairs off a counter kept in `state`, which
  *                           the call zeroes: two SpMM calls that share a `state` must not
  *                           overlap (calls in one stream never do).
+ *   sgnn_spmm_tilegroup_slices_f32  the same product for the operand's 128-feature slices
+ *                           slice_begin .. slice_begin + slice_count - 1 only (slice_count <= 0:
+ *                           to the last): a row partition whose operand arrives slice by slice
+ *                           multiplies a slice while the next one travels.  All pointers and F
+ *                           describe the whole operand as in sgnn_spmm_tilegroup_f32; ranges of
+ *                           one operand go in ascending order on one stream (the range that
+ *                           holds slice 0 clears state_out); a range that is not the whole
+ *                           operand has no fall-back (rowptr must be NULL).  reserve_cus: the
+ *                           launch leaves that many CUs without a workgroup, for kernels of
+ *                           other streams (a collective) that must make progress beside it --
+ *                           a workgroup of this kernel holds its CU until the launch's work
+ *                           is done.
  *   sgnn_tilegroup_chain_f32  Y = A_hat^K . X (utils.py:91-96, model/SGC.py:11): one split of X,
  *                           K hops of which only the last writes fp32 -- the others write the
  *                           next hop's planes from their epilogue, so no intermediate is
@@ -306,6 +318,16 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
                             void* csr_workspace, size_t csr_workspace_bytes, int64_t x_row_offset, const float* addend,
                             int64_t ld_addend, void* planes_out, int64_t planes_out_rows, int64_t out_row_offset,
                             void* state_out, int adapt, void* stream);
+int sgnn_spmm_tilegroup_slices_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
+                                   int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
+                                   const float* dinv_row, float w_off, const float* corr, const void* planes,
+                                   size_t planes_bytes, void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                                   size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                                   const float* vals, const float* dinv_col, const float* X, int64_t ldx,
+                                   void* csr_workspace, size_t csr_workspace_bytes, int64_t x_row_offset, const float* addend,
+                                   int64_t ld_addend, void* planes_out, int64_t planes_out_rows, int64_t out_row_offset,
+                                   void* state_out, int adapt, int64_t slice_begin, int64_t slice_count, int reserve_cus,
+                                   void* stream);
 int sgnn_tilegroup_chain_f32(int K, int64_t n, int64_t F, const void* plan, size_t plan_bytes, int64_t stages,
                              int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups, const float* dinv,
                              float w_off, const float* corr, const float* X, int64_t ldx, float* Y, int64_t ldy,

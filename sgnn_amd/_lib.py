@@ -82,6 +82,12 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                                         c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int,
                                         c_void_p]),
+    "sgnn_spmm_tilegroup_slices_f32": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_size_t, c_int64, c_int64, c_int64,
+                                               c_int64, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_size_t, c_void_p,
+                                               c_void_p, c_int64, c_int, c_void_p, c_size_t, c_int64, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                                               c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int,
+                                               c_int64, c_int64, c_int, c_void_p]),
     "sgnn_tilegroup_chain_f32": (c_int, [c_int, c_int64, c_int64, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_int64,
                                          c_int64, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,

@@ -760,6 +760,11 @@ struct TgArgs {
   const char* planes;
   TgState* state;    // of the operand in `planes`
   uint32_t* queue;   // work counter of this launch (in the state words)
+  // per-feature words of the two states, from the launch's first feature on (a launch may cover a
+  // range of the operand's 128-feature slices: every pointer below is then moved to the range's
+  // first slice on the host and F, Fpad, slices describe the range)
+  const uint32_t *amax_in, *bound_in;
+  uint32_t *amax_out, *bound_out;
   const float* dinv_row;
   // diagonal of its own (A + A^T has weight 2 off the diagonal, A + I puts 1 on it): the
   // weighted row sum is w_off * (pattern sum) + corr[i] * x'_i with x' the operand as the
@@ -1185,8 +1190,8 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   u32x4 mx4 = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const uint32_t bnd = bound_of(a.state, a.Fpad)[f0 + i];
-    const uint32_t nxt = (to_planes && a.adapt) ? a.state->amax[f0 + i] : bnd;
+    const uint32_t bnd = a.bound_in[f0 + i];
+    const uint32_t nxt = (to_planes && a.adapt) ? a.amax_in[f0 + i] : bnd;
     const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
     inv4[i] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);   // 1 / scale, exact: a power of two
     sc4[i] = tg_scale(nxt);
@@ -1389,7 +1394,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     if (tid < kSlice) {
       const uint32_t m = *lds<uint32_t>(uint32_t(kAmaxOff) + uint32_t(tid) * 4u);
       if (m) {
-        atomicMax(&a.state_out->amax[slice * kSlice + tid], m);
+        atomicMax(&a.amax_out[slice * kSlice + tid], m);
         *lds<uint32_t>(uint32_t(kAmaxOff) + uint32_t(tid) * 4u) = 0u;
       }
     }
@@ -1425,7 +1430,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     for (int sl = blockIdx.x; sl < a.slices; sl += gridDim.x)
       if (threadIdx.x < kSlice) {
         const int f = sl * kSlice + threadIdx.x;
-        bound_of(a.state_out, a.Fpad)[f] = a.adapt ? a.state->amax[f] : bound_of(a.state, a.Fpad)[f];
+        a.bound_out[f] = a.adapt ? a.amax_in[f] : a.bound_in[f];
       }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.state_out->tiny_limit = a.tiny_limit_out;
   }
@@ -1540,8 +1545,8 @@ __global__ __launch_bounds__(1024) void k_tg_combine(TgArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int f = f4 + j;
-        const uint32_t bnd = f < a.F ? bound_of(a.state, a.Fpad)[f] : 0u;
-        nb[j] = (to_planes && a.adapt && f < a.F) ? a.state->amax[f] : bnd;
+        const uint32_t bnd = f < a.F ? a.bound_in[f] : 0u;
+        nb[j] = (to_planes && a.adapt && f < a.F) ? a.amax_in[f] : bnd;
         const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
         inv_in[j] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);
       }
@@ -1620,7 +1625,7 @@ __global__ __launch_bounds__(1024) void k_tg_combine(TgArgs a) {
       for (int j = 0; j < 4; ++j)
         if (mx[j] && f4 + j < a.F) {
           if (f4 + j < 4096 && rows_par > 1) atomicMax(&smax[f4 + j], mx[j]);
-          else atomicMax(&a.state_out->amax[f4 + j], mx[j]);
+          else atomicMax(&a.amax_out[f4 + j], mx[j]);
         }
     }
     if (int(blockDim.x) >= quads) break;   // one set of features per thread
@@ -1629,7 +1634,7 @@ __global__ __launch_bounds__(1024) void k_tg_combine(TgArgs a) {
     if (rows_par > 1) {
       __syncthreads();
       for (int f = threadIdx.x; f < a.F && f < 4096; f += blockDim.x)
-        if (smax[f]) atomicMax(&a.state_out->amax[f], smax[f]);
+        if (smax[f]) atomicMax(&a.amax_out[f], smax[f]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
@@ -1874,16 +1879,17 @@ size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F) {
   return align_up(size_t(partial_slots) * kRows * size_t(Fpad) * 4 + 256);
 }
 
-int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
-                            int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
-                            const float* dinv_row, float w_off, const float* corr, const void* planes,
-                            size_t planes_bytes,
-                            void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
-                            size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
-                            const float* vals, const float* dinv_col, const float* X, int64_t ldx,
-                            void* csr_workspace, size_t csr_workspace_bytes, int64_t x_row_offset, const float* addend,
-                            int64_t ld_addend, void* planes_out, int64_t planes_out_rows, int64_t out_row_offset,
-                            void* state_out, int adapt, void* stream) {
+int sgnn_spmm_tilegroup_slices_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
+                                   int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
+                                   const float* dinv_row, float w_off, const float* corr, const void* planes,
+                                   size_t planes_bytes,
+                                   void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                                   size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                                   const float* vals, const float* dinv_col, const float* X, int64_t ldx,
+                                   void* csr_workspace, size_t csr_workspace_bytes, int64_t x_row_offset, const float* addend,
+                                   int64_t ld_addend, void* planes_out, int64_t planes_out_rows, int64_t out_row_offset,
+                                   void* state_out, int adapt, int64_t slice_begin, int64_t slice_count, int reserve_cus,
+                                   void* stream) {
   if (n_rows <= 0 || n_cols <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty problem");
   if (!plan || !planes || !state) return fail(SGNN_ERR_INVALID, "null pointer");
   if (!planes_out && !Y) return fail(SGNN_ERR_INVALID, "neither Y nor planes_out given");
@@ -1909,7 +1915,17 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   if (partial_slots > 0 && (!workspace || workspace_bytes < sgnn_spmm_tilegroup_workspace_bytes(partial_slots, F)))
     return fail(SGNN_ERR_WORKSPACE, "tile-group spmm workspace too small");
   if (reinterpret_cast<uintptr_t>(workspace) % 16) return fail(SGNN_ERR_INVALID, "workspace must be 16-byte aligned");
-  const int64_t slices = (F + kSlice - 1) / kSlice;
+  const int64_t all_slices = (F + kSlice - 1) / kSlice;
+  if (slice_count <= 0) slice_count = all_slices - slice_begin;
+  if (slice_begin < 0 || slice_begin >= all_slices || slice_begin + slice_count > all_slices)
+    return fail(SGNN_ERR_INVALID, "slice range outside the operand");
+  if (reserve_cus < 0) return fail(SGNN_ERR_INVALID, "negative number of reserved CUs");
+  const bool part = slice_begin != 0 || slice_count != all_slices;
+  if (part && rowptr != nullptr) return fail(SGNN_ERR_INVALID, "a launch over a range of slices has no fall-back");
+  const int64_t f_base = slice_begin * kSlice;                                  // the range's first feature
+  const int64_t F_all = F, Fpad_all = all_slices * kSlice;
+  F = (F_all - f_base < slice_count * kSlice) ? F_all - f_base : slice_count * kSlice;   // features of the range
+  const int64_t slices = slice_count;
   if (slices * items >= (int64_t(1) << 31)) return fail(SGNN_ERR_INVALID, "too many workgroups for one launch");
   TgArgs a{};
   a.plan_counts = p.counts;
@@ -1917,23 +1933,30 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
   a.step_slots = p.step_slots; a.step_bits = p.step_bits;
   a.item_group = p.item_group; a.item_s0 = p.item_s0; a.item_s1 = p.item_s1; a.item_out = p.item_out;
   a.long_group = p.long_group; a.long_slot = p.long_slot; a.long_nseg = p.long_nseg;
-  a.planes = static_cast<const char*>(planes);
+  a.slice_bytes = n_cols * kRowBytes;
+  a.slice_bytes_out = planes_out_rows * int64_t(kRowBytes);
+  a.planes = static_cast<const char*>(planes) + slice_begin * a.slice_bytes;
   a.state = static_cast<TgState*>(state);
   a.queue = &static_cast<TgState*>(state)->queue;
-  a.dinv_row = dinv_row; a.Y = Y; a.partial = static_cast<float*>(workspace);
-  a.corr = corr; a.X = X; a.dinv_col = dinv_col; a.ldx = ldx;
-  a.addend = addend; a.ld_addend = ld_addend;
-  a.planes_out = static_cast<char*>(planes_out);
+  a.amax_in = a.state->amax + f_base;
+  a.bound_in = a.state->amax + Fpad_all + f_base;   // (addresses only: the bounds follow the maxima)
+  a.dinv_row = dinv_row; a.Y = Y ? Y + f_base : nullptr; a.partial = static_cast<float*>(workspace);
+  a.corr = corr; a.X = X ? X + f_base : nullptr; a.dinv_col = dinv_col; a.ldx = ldx;
+  a.addend = addend ? addend + f_base : nullptr; a.ld_addend = ld_addend;
+  a.planes_out = planes_out ? static_cast<char*>(planes_out) + slice_begin * a.slice_bytes_out : nullptr;
   a.state_out = static_cast<TgState*>(state_out);
-  a.slice_bytes_out = planes_out_rows * int64_t(kRowBytes);
+  if (a.state_out != nullptr) {
+    a.amax_out = a.state_out->amax + f_base;
+    a.bound_out = a.state_out->amax + Fpad_all + f_base;
+  }
   a.x_row_offset = x_row_offset; a.out_row_offset = out_row_offset; a.n_rows = n_rows;
-  a.ldy = ldy; a.slice_bytes = n_cols * kRowBytes;
+  a.ldy = ldy;
   a.items = int32_t(items); a.n_long = int32_t(long_groups);
   a.stages = int32_t(stages); a.steps = int32_t(steps);
   a.F = int32_t(F); a.Fpad = int32_t(slices * kSlice); a.epilogue = epilogue; a.w_off = w_off;
   a.mode = g_tg_mode;
   a.slices = int32_t(slices);
-  a.tiny_limit_out = tg_tiny_limit(planes_out_rows * F);
+  a.tiny_limit_out = tg_tiny_limit(planes_out_rows * F_all);
   a.adapt = adapt ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // per device: the attribute belongs to the device's copy of the kernel, and the number of
@@ -1950,11 +1973,16 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
     if (n_cus <= 0) n_cus = 256;
     cus_of[dev].store(n_cus, std::memory_order_release);
   }
-  if (planes_out != nullptr) HIP_TRY(hipMemsetAsync(state_out, 0, tg_state_live_bytes(slices * kSlice), st));
+  // (the next operand's state is cleared by the launch that covers the operand's first slice:
+  // launches over ranges of slices go in ascending order on one stream)
+  if (planes_out != nullptr && slice_begin == 0) HIP_TRY(hipMemsetAsync(state_out, 0, tg_state_live_bytes(Fpad_all), st));
   HIP_TRY(hipMemsetAsync(a.queue, 0, 9 * sizeof(uint32_t), st));   // the work counters: one for the launch, one per XCD
   // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
   sgnn::kernel_timer_begin(st);
-  const int64_t wgs = (items * slices < n_cus || (a.mode & 128)) ? items * slices : n_cus;
+  // (reserve_cus: CUs left to kernels of other streams -- a collective that runs beside this
+  // launch finds no CU once the workgroups of this one hold them all until the work is done)
+  const int64_t mine = n_cus - reserve_cus > 8 ? n_cus - reserve_cus : 8;
+  const int64_t wgs = (items * slices < mine || (a.mode & 128)) ? items * slices : mine;
   hipLaunchKernelGGL(k_tg_spmm, dim3(unsigned(wgs)), dim3(kWaves * kWave), kLdsBytes, st, a);
   HIP_TRY(hipGetLastError());
   sgnn::kernel_timer_end(st);
@@ -1971,10 +1999,27 @@ int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const voi
     // operand, behind the same flag (its kernels return at once while the flag is 0)
     if (!colidx || !X || !Y) return fail(SGNN_ERR_INVALID, "null pointer");
     if (addend != nullptr) return fail(SGNN_ERR_INVALID, "a launch with an addend has no fall-back");
-    return spmm_csr_guarded(n_rows, n_cols, nnz, F, rowptr, colidx, vals, dinv_row, dinv_col, X, ldx, Y, ldy, epilogue,
+    return spmm_csr_guarded(n_rows, n_cols, nnz, F_all, rowptr, colidx, vals, dinv_row, dinv_col, X, ldx, Y, ldy, epilogue,
                             csr_workspace, csr_workspace_bytes, &static_cast<const TgState*>(state)->flag, st);
   }
   return SGNN_OK;
+}
+
+int sgnn_spmm_tilegroup_f32(int64_t n_rows, int64_t n_cols, int64_t F, const void* plan, size_t plan_bytes,
+                            int64_t stages, int64_t steps, int64_t items, int64_t partial_slots, int64_t long_groups,
+                            const float* dinv_row, float w_off, const float* corr, const void* planes,
+                            size_t planes_bytes,
+                            void* state, float* Y, int64_t ldy, int epilogue, void* workspace,
+                            size_t workspace_bytes, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                            const float* vals, const float* dinv_col, const float* X, int64_t ldx,
+                            void* csr_workspace, size_t csr_workspace_bytes, int64_t x_row_offset, const float* addend,
+                            int64_t ld_addend, void* planes_out, int64_t planes_out_rows, int64_t out_row_offset,
+                            void* state_out, int adapt, void* stream) {
+  return sgnn_spmm_tilegroup_slices_f32(n_rows, n_cols, F, plan, plan_bytes, stages, steps, items, partial_slots, long_groups,
+                                        dinv_row, w_off, corr, planes, planes_bytes, state, Y, ldy, epilogue, workspace,
+                                        workspace_bytes, nnz, rowptr, colidx, vals, dinv_col, X, ldx, csr_workspace,
+                                        csr_workspace_bytes, x_row_offset, addend, ld_addend, planes_out, planes_out_rows,
+                                        out_row_offset, state_out, adapt, 0, 0, 0, stream);
 }
 
 int sgnn_tilegroup_chain_f32(int K, int64_t n, int64_t F, const void* plan, size_t plan_bytes, int64_t stages,

@@ -29,7 +29,10 @@ large and shared enough for the tile-group (matrix-core) kernel, what travels is
 rows but the operand's fp16 planes (the same four bytes per element), one all-gather per
 128-feature slice: a rank splits only its own rows, after the ranks have agreed on the
 per-feature maxima with one small all-reduce, and on later hops the epilogue writes the
-rank's rows of the next operand straight into its piece of the next gather buffer.
+rank's rows of the next operand straight into its piece of the next gather buffer.  The
+planes travel in units of ``slices_per_exchange`` slices and the remote-columns block is
+multiplied unit by unit as they land, so that only the last unit's multiply follows the last
+byte; launches that run beside an exchange leave ``reserve_cus`` CUs to the collective.
 
 Blocks are padded to a common row count so that the exchange is ONE
 ``all_gather_into_tensor`` of equal pieces; node ids are remapped once into the
@@ -192,6 +195,8 @@ class PartitionedAdj:
         self._gather = {}
         self._slice_bufs = {}
         self._comm_stream = None
+        self.reserve_cus = 32                   # see _reserved_cus
+        self.slices_per_exchange = 2            # 128-feature slices per exchange / multiply unit of the planes schedule
 
     # ------------------------------------------------------------------ build
     @classmethod
@@ -380,6 +385,15 @@ class PartitionedAdj:
             self._comm_stream = torch.cuda.Stream(device=device)
         return torch.cuda.current_stream(device), self._comm_stream
 
+    def _reserved_cus(self):
+        """CUs the matrix-core kernel leaves free while an exchange runs beside it: its
+        workgroups hold their CU (all of its LDS) until the launch's work is done, so a
+        collective kernel that arrives later would otherwise wait for the multiply to end.
+        Nothing to reserve where the exchange is staged through the host (gloo)."""
+        if self.world == 1 or not dist.is_initialized() or dist.get_backend(self.group) == "gloo":
+            return 0
+        return int(self.reserve_cus)
+
     def _propagate_split(self, X_local, order):
         """Exchange of fp32 rows overlapped with the own-columns multiply: the own-columns block
         reads only the rank's own (already scaled) rows, so it starts at once on the compute
@@ -476,11 +490,11 @@ class PartitionedAdj:
             b["states"] = torch.zeros((order, b["sb"] // 4), dtype=torch.int32, device=device)
         return b
 
-    def _exchange_planes(self, G):
-        """One exchange per 128-feature slice: a slice of the operand is [padded nodes, 512 bytes]
-        and the rank's piece of it is contiguous."""
+    def _exchange_planes(self, G, s0=0, s1=None):
+        """One exchange per 128-feature slice (slices s0 .. s1 - 1): a slice of the operand is
+        [padded nodes, 512 bytes] and the rank's piece of it is contiguous."""
         lo = self.rank * self.max_rows if self.halo is None else 0
-        for s in range(G.shape[0]):
+        for s in range(s0, G.shape[0] if s1 is None else s1):
             full = G[s]
             if self.halo is None:
                 self._all_gather(full, full[lo:lo + self.max_rows])
@@ -489,6 +503,9 @@ class PartitionedAdj:
 
     def _propagate_planes(self, X_local, order):
         """Local-block overlap with the operand exchanged as fp16 planes (see the module text).
+        The operand travels in units of ``slices_per_exchange`` 128-feature slices, and the
+        remote-columns block is multiplied unit by unit as they land: the multiply of one unit
+        runs while the next is on the wire.
         Returns None when some rank's operand could not go through the planes (non-finite
         values, a dynamic range fp16 pairs cannot hold): the caller then runs the fp32 schedule."""
         lib = _lib.load()
@@ -499,6 +516,10 @@ class PartitionedAdj:
         n_cols = self.local.n_cols
         lo = self.rank * self.max_rows if self.halo is None else 0
         Fpad = (F + 127) // 128 * 128
+        S = Fpad // 128
+        per = max(1, int(self.slices_per_exchange))
+        units = [(s, min(per, S - s)) for s in range(0, S, per)]
+        reserve = self._reserved_cus()
         st = _lib.current_stream(dev)
         main, comm = self._streams(dev)
         states = b["states"]
@@ -514,40 +535,51 @@ class PartitionedAdj:
             amax.copy_(host)
         else:
             dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)
-        piece0 = b["G"][0][:, lo:lo + self.max_rows]
         _lib.check(lib.sgnn_tilegroup_planes_f32(rows, F, _lib.ptr(dinv), _lib.ptr(X_local), X_local.stride(0),
                                                  ctypes_ptr(b["flat"][0], lo * 512), n_cols, rows, _lib.ptr(states[0]), st))
-        del piece0
         out = torch.empty((rows, F), dtype=torch.float32, device=dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        written = [ready] * len(units)            # when the rank's own rows of a unit's slices are in the gather buffer
         for h in range(order):
             G, flat, state = b["G"][h % 2], b["flat"][h % 2], states[h]
             last = h == order - 1
-            ready = torch.cuda.Event()
-            ready.record(main)
+            landed = []
             with torch.cuda.stream(comm):
-                comm.wait_event(ready)
-                self._exchange_planes(G)
-                done = torch.cuda.Event()
-                done.record(comm)
+                for u, (s0, cnt) in enumerate(units):
+                    comm.wait_event(written[u])
+                    self._exchange_planes(G, s0, s0 + cnt)
+                    ev = torch.cuda.Event()
+                    ev.record(comm)
+                    landed.append(ev)
             # own-columns block: raw pattern sums into s1, from the rank's own rows of the planes
             po = own._tg
-            _lib.check(lib.sgnn_spmm_tilegroup_f32(
+            _lib.check(lib.sgnn_spmm_tilegroup_slices_f32(
                 rows, n_cols, F, _lib.ptr(po["buf"]), po["bytes"], po["stages"], po["steps"], po["items"], po["slots"],
                 po["n_long"], None, 1.0, None, _lib.ptr(flat), b["nbytes"], _lib.ptr(state), _lib.ptr(b["s1"]), F,
                 _lib.EPI_SCALE_ROW, _lib.ptr(b["ws_own"]), b["ws_own"].numel(), own.adj.nnz, None, None, None, None, None, 0,
-                None, 0, 0, None, 0, None, 0, 0, None, 0, st))
-            main.wait_event(done)
-            # remote-columns block: + s1, weights, diagonal correction, row scaling; the last hop
-            # writes fp32, the others the rank's rows of the next operand's planes
+                None, 0, 0, None, 0, None, 0, 0, None, 0, 0, 0, reserve, st))
+            # remote-columns block, unit by unit as the slices land: + s1, weights, diagonal
+            # correction, row scaling; the last hop writes fp32, the others the rank's rows of the
+            # next operand's planes
             pr = rem._tg
             nxt = b["flat"][(h + 1) % 2]
-            _lib.check(lib.sgnn_spmm_tilegroup_f32(
-                rows, n_cols, F, _lib.ptr(pr["buf"]), pr["bytes"], pr["stages"], pr["steps"], pr["items"], pr["slots"],
-                pr["n_long"], _lib.ptr(dinv), float(own.adj.w_off), _lib.ptr(own.adj.corr), _lib.ptr(flat), b["nbytes"],
-                _lib.ptr(state), _lib.ptr(out) if last else None, F,
-                _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2, _lib.ptr(b["ws_rem"]), b["ws_rem"].numel(),
-                rem.adj.nnz, None, None, None, None, None, 0, None, 0, lo, _lib.ptr(b["s1"]), F,
-                None if last else _lib.ptr(nxt), n_cols, lo, None if last else _lib.ptr(states[h + 1]), 0, st))
+            written_next = []
+            for u, (s0, cnt) in enumerate(units):
+                main.wait_event(landed[u])
+                _lib.check(lib.sgnn_spmm_tilegroup_slices_f32(
+                    rows, n_cols, F, _lib.ptr(pr["buf"]), pr["bytes"], pr["stages"], pr["steps"], pr["items"], pr["slots"],
+                    pr["n_long"], _lib.ptr(dinv), float(own.adj.w_off), _lib.ptr(own.adj.corr), _lib.ptr(flat), b["nbytes"],
+                    _lib.ptr(state), _lib.ptr(out) if last else None, F,
+                    _lib.EPI_SCALE_ROW if last else _lib.EPI_SCALE_ROW2, _lib.ptr(b["ws_rem"]), b["ws_rem"].numel(),
+                    rem.adj.nnz, None, None, None, None, None, 0, None, 0, lo, _lib.ptr(b["s1"]), F,
+                    None if last else _lib.ptr(nxt), n_cols, lo, None if last else _lib.ptr(states[h + 1]), 0,
+                    s0, cnt, reserve if (u + 1 < len(units) or not last) else 0, st))
+                if not last:                      # the next hop's exchange of this unit may start
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    written_next.append(ev)
+            written = written_next
         # one agreement per call: did every rank's every operand go through the planes?
         head = states[:order, :8].cpu()           # synchronises
         refused = bool((head[:, _lib.TG_STATE_FLAG] != 0).any()

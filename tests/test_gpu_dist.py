@@ -127,7 +127,10 @@ def test_one_block_schedule_with_the_plain_kernel_is_bit_identical_to_one_gpu(gp
 
 @pytest.mark.parametrize("world,F,order,w,exchange", [
     (2, 128, 2, None, "allgather"), (2, 200, 3, 2.0, "allgather"), (4, 96, 2, None, "allgather"),
-    (2, 130, 2, 2.0, "referenced"), (2, 41, 2, None, "referenced")])
+    (2, 130, 2, 2.0, "referenced"), (2, 41, 2, None, "referenced"),
+    # three and five 128-feature slices: the operand travels in units of two slices and the
+    # remote-columns block is multiplied unit by unit (last unit: one slice, of 44 / 90 features)
+    (2, 300, 2, 2.0, "allgather"), (2, 602, 3, None, "allgather"), (4, 602, 2, 2.0, "referenced")])
 def test_planes_exchange_on_one_gpu_matches_single(gpu_device, world, F, order, w, exchange):
     """The matrix-core schedule of the partition, forced on a small graph: every rank splits only
     its own rows (after the ranks agreed on the per-feature maxima), fp16 planes travel slice by

@@ -1,5 +1,9 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -u tools/grouping_probe.py reddit 512 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_grouping_probe.txt || exit 1
-timeout -k 10 500 python -u tools/grouping_probe.py products 512 2>&1 | grep -v amdgpu.ids >> gpurun_out/r03_grouping_probe.txt || exit 1
-cat gpurun_out/r03_grouping_probe.txt
+export SGNN_BENCH_REHEARSAL=1
+timeout -k 10 800 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 4 --steps 5 --warmup 2 > gpurun_out/r03_rehearsal4.json 2> gpurun_out/r03_rehearsal4.err || { tail -20 gpurun_out/r03_rehearsal4.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r03_rehearsal4.json').read().strip().splitlines()[-1])
+print(d['config']['overlap'], d['config'].get('exchange_unit_slices'), d['config'].get('reserved_cus_beside_exchange'), d['ms_per_step'])
+PY
