@@ -275,3 +275,68 @@ def test_launch_counts_that_do_not_match_the_plan_raise_the_flag(gpu_device):
     adj.use_tilegroup, adj.use_rowgroup = False, False
     assert torch.equal(Y, adj.spmm(X))                   # the fall-back computed it
     assert float((Y - Y_good).norm() / Y_good.norm()) <= TOL
+
+
+@pytest.mark.parametrize("weight,to_planes", [(None, False), (2.0, False), (2.0, True)])
+def test_slice_ranges_equal_the_whole_launch_bit_for_bit(gpu_device, weight, to_planes):
+    """sgnn_spmm_tilegroup_slices_f32 over ranges of the operand's 128-feature slices, in ascending
+    order on one stream, against the one launch over all of them: a slice's rows are computed by
+    the same units of work either way, so Y (or the next operand's planes, maxima, bounds and tiny
+    count) must come out bit-identical.  F = 602: five slices, the last of 90 features; ranges of
+    2 + 1 + 2 slices; the hub rows of the graph split groups, so k_tg_combine runs per range too."""
+    from sgnn_amd import _lib
+    from sgnn_amd.norm_adj import tilegroup_buffers
+    lib = _lib.load()
+    n, F = 6000, 602
+    adj, r, c, v = _graph(n, 700_000, seed=21, dev=gpu_device, weight=weight)
+    X = torch.randn(n, F, device=gpu_device)
+    adj.propagate(X, 1)                                    # builds the plan
+    plan = adj._tg
+    assert plan and plan["n_long"] > 0, "the graph should split some groups"
+    st = _lib.current_stream(gpu_device)
+    sb = lib.sgnn_tilegroup_state_bytes(F)
+    pl_bytes = lib.sgnn_tilegroup_planes_bytes(n, F)
+    ws = torch.empty(max(lib.sgnn_spmm_tilegroup_workspace_bytes(plan["slots"], F), 256), dtype=torch.uint8, device=gpu_device)
+    planes = torch.empty(pl_bytes, dtype=torch.uint8, device=gpu_device)
+    state = torch.zeros(sb // 4, dtype=torch.int32, device=gpu_device)
+    _lib.check(lib.sgnn_tilegroup_split_f32(n, F, _lib.ptr(adj.dinv), _lib.ptr(X), F, _lib.ptr(planes), pl_bytes,
+                                            _lib.ptr(state), st))
+    corr = getattr(adj, "corr", None)
+
+    def run(ranges):
+        Y = torch.zeros(n, F, device=gpu_device)
+        out_planes = torch.zeros(pl_bytes, dtype=torch.uint8, device=gpu_device) if to_planes else None
+        out_state = torch.full((sb // 4,), -1, dtype=torch.int32, device=gpu_device) if to_planes else None
+        for s0, cnt in ranges:
+            _lib.check(lib.sgnn_spmm_tilegroup_slices_f32(
+                n, n, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"], plan["slots"],
+                plan["n_long"], _lib.ptr(adj.dinv), float(adj.w_off), _lib.ptr(corr), _lib.ptr(planes), pl_bytes,
+                _lib.ptr(state), None if to_planes else _lib.ptr(Y), F,
+                _lib.EPI_SCALE_ROW2 if to_planes else _lib.EPI_SCALE_ROW, _lib.ptr(ws), ws.numel(), adj.nnz,
+                None, None, None, _lib.ptr(adj.dinv), _lib.ptr(X), F, None, 0, 0, None, 0,
+                _lib.ptr(out_planes) if to_planes else None, n, 0, _lib.ptr(out_state) if to_planes else None, 1,
+                s0, cnt, 0, st))
+        torch.cuda.synchronize()
+        assert int(state[_lib.TG_STATE_FLAG].item()) == 0
+        if to_planes:
+            Fpad = (F + 127) // 128 * 128
+            live = 16 + 2 * Fpad                            # header, maxima, bounds (the scratch behind them is not written)
+            head = out_state[:live].clone()
+            head[7:16] = 0                                  # the work counters of the next operand's launches
+            return out_planes, head
+        return Y, None
+
+    whole, whole_state = run([(0, 0)])
+    parts, parts_state = run([(0, 2), (2, 1), (3, 2)])
+    assert torch.equal(whole, parts)
+    if to_planes:
+        assert torch.equal(whole_state, parts_state)
+        assert int(whole_state[_lib.TG_STATE_FLAG].item()) == 0
+    # a range that is not the whole operand has no fall-back of its own, and ranges must lie inside the operand
+    with pytest.raises(_lib.SgnnHipError):
+        _lib.check(lib.sgnn_spmm_tilegroup_slices_f32(
+            n, n, F, _lib.ptr(plan["buf"]), plan["bytes"], plan["stages"], plan["steps"], plan["items"], plan["slots"],
+            plan["n_long"], _lib.ptr(adj.dinv), float(adj.w_off), _lib.ptr(corr), _lib.ptr(planes), pl_bytes,
+            _lib.ptr(state), _lib.ptr(whole if not to_planes else torch.zeros(n, F, device=gpu_device)), F, _lib.EPI_SCALE_ROW,
+            _lib.ptr(ws), ws.numel(), adj.nnz, None, None, None, None, None, 0, None, 0, 0, None, 0, None, 0, 0, None, 1,
+            4, 2, 0, st))
