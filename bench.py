@@ -647,6 +647,10 @@ def main():
             b_alg = nnz // rr * 8 + (n // rr + 1) * 4 + 2 * (n // rr) * 4 + n * fr * 4 + (n // rr) * fr * 4
         launches_per_step = (k_n / args.steps) if k_n else args.order
         kernel_ms = k_ms if k_ms else ev_ms / launches_per_step
+        if world > 1 and k_ms:
+            # a rank's hop is several launches of the main kernel (own-columns block, remote-columns
+            # block unit by unit): what is priced against the rank's bytes is their sum per hop
+            kernel_ms = k_ms * launches_per_step / args.order
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
         key = args.workload + ("" if args.max_degree is None else f"_clip{args.max_degree}") \
             + ("" if args.weight is None else f"_w{args.weight:g}")
@@ -694,7 +698,9 @@ def main():
                 "frac_whole_step": b_alg * args.order / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,   # N > 1: exchange included
                 "kernels_in_step": kernels_in_step,
                 "gather_bytes_no_reuse": nnz * F * 4,
-                **({} if world == 1 else {"scope": "one rank's launch of the main kernel"}),
+                **({} if world == 1 else {"scope": "one rank: kernel_ms is the sum of its launches of the main kernel per hop, "
+                                                    "algorithmic_bytes its share of the CSR and of Y plus the operand it reads",
+                                          "kernel_launches_per_hop": launches_per_step / args.order}),
             },
         }
         roof = out["roofline"]
