@@ -17,13 +17,21 @@ classification stack and one of the clustering (auto-encoder) stack at the refer
 10 000 optimiser iterations per layer run.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU) splits the same job
-over the ranks (strong scaling).  The headline is always the pure row partition:
-every rank owns a block of rows of the graph, multiplies its own-columns block while the
-other ranks' rows of the operand travel over RCCL (as fp16 planes, one all-gather per
-128-feature slice, where the matrix-core kernel applies; as fp32 rows otherwise) and its
-remote-columns block when they have landed (``config.overlap`` names the schedule that
-ran; ``--slices k`` lets the feature-sliced pipeline compete).  Grids that also split the feature
-columns (feature_groups x row_ranks) are timed for a few steps each and reported as
+over the ranks (strong scaling).  Two schedules that serve the same caller (each rank hands
+in its rows of X and gets its rows of the result) are probed for a few steps and the faster
+one is benchmarked:
+* the row partition: every rank owns a block of rows of the graph, multiplies its
+  own-columns block while the other ranks' rows of the operand travel over RCCL (as fp16
+  planes, one all-gather per 128-feature slice, where the matrix-core kernel applies; as
+  fp32 rows otherwise) and its remote-columns block as they land (``--slices k`` lets the
+  older feature-sliced pipeline compete inside it);
+* the feature split: every rank holds the whole graph and propagates F / N columns; two
+  all-to-alls per call carry the caller's rows to column slices and back, no exchange
+  between hops (``--no-feature-split`` keeps it out).
+``config.rows`` / ``config.overlap`` / ``config.collective`` name what ran,
+``config.row_partition_ms_per_step`` keeps the row partition's probe time when the other
+schedule won.  Grids that split rows and features (feature_groups x row_ranks, no
+all-to-all: X is assumed to live in feature slices already) are timed too and reported as
 ``grid_probe_ms`` extras only.
 """
 from __future__ import annotations
@@ -399,6 +407,9 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["allgather", "referenced", "auto"],
                     help="N > 1: rows of X a rank receives per hop: all of them (one all-gather), only the ones its "
                          "block references (all-to-all), or the latter where it saves at least 40 %% of the bytes")
+    ap.add_argument("--no-feature-split", action="store_true",
+                    help="N > 1: do not let the feature-split schedule (whole graph on every rank, F / N columns each, "
+                         "two all-to-alls per call) compete with the row partition for the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the other shapes and the SGNN epoch")
     ap.add_argument("--epoch-iters", type=int, default=10000,
@@ -530,8 +541,30 @@ def main():
             return best
 
         probed = {}
-        # the headline: the pure row partition, all `world` ranks in one all-gather
-        _, step, info = probe_grid(1, probed)
+        # Two ways to use the ranks compete for the headline, both serving a caller who owns rows
+        # of X and both exchanging over the job's collective backend: the row partition (all
+        # `world` ranks in one exchange per hop, overlapped with the multiply) and the feature
+        # split (every rank holds the graph and propagates F / world columns; two all-to-alls per
+        # call carry the rows there and back).
+        t_row, step, info = probe_grid(1, probed)
+        fs = None
+        if not args.no_feature_split:
+            from sgnn_amd.dist import FeatureSplitAdj
+            t0 = time.perf_counter()
+            fadj = FeatureSplitAdj.from_coo(row, col, None, n, device, rank, world)
+            torch.cuda.synchronize()
+            fs_build_ms = (time.perf_counter() - t0) * 1e3
+            Xf = X[fadj.rows.to(device)].contiguous()
+            fs_step = lambda: fadj.propagate(Xf, args.order)      # noqa: E731
+            t_fs = probe(fs_step)
+            probed["feature-split"] = round(t_fs * 1e3, 3)
+            if rank == 0:
+                log(f"feature split over {world} ranks (whole graph per rank, two all-to-alls per call): built in "
+                    f"{fs_build_ms:.0f} ms, probe {t_fs * 1e3:.2f} ms/step; row partition {t_row * 1e3:.2f} ms/step")
+            if t_fs < t_row:
+                fs = (fadj, fs_step, fs_build_ms)
+            else:
+                del fadj, Xf
         if args.feature_groups == 0:
             others = [g for g in range(2, world + 1) if world % g == 0 and g <= F]
         else:
@@ -542,48 +575,71 @@ def main():
         del row, col, X
         nnz, max_deg = info.pop("nnz"), info.pop("max_deg")
         padj = info.pop("_padj")
-        local = padj.local            # which kernel the rank-local multiply took (decided on first use)
-        extra.update(info)
-        step()                                     # (sets padj.last_schedule for the schedule benchmarked)
-        # which schedule the timed steps run: "local-block" = own-columns block multiplied while the
-        # exchange runs, remote-columns block when it lands (with fp16 planes exchanged where the
-        # matrix-core kernel applies); "sliced" = feature slices pipelined; "none" = exchange, then multiply
-        extra["overlap"] = padj.last_schedule
-        extra["collective"] = (f"{info['exchange']} among {info['exchange_ranks']} ranks, backend "
-                               f"{dist.get_backend()} ({'gloo rehearsal on one GPU' if rehearsal else 'RCCL'}), "
-                               f"world size {dist.get_world_size()}")
-        if rank == 0:
-            log(f"headline: row partition over {info['exchange_ranks']} ranks, overlap {extra['overlap']}; {extra['collective']}")
-        if len(probed) > 1:
-            extra["grid_probe_ms"] = probed
-        lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
-        planes = padj.last_schedule is not None and "planes" in padj.last_schedule
-        if planes:
-            Fr = extra["features_per_rank"]
-            extra["exchange_bytes_per_rank_per_hop"] = (
-                (padj.max_rows * padj.world if padj.halo is None else padj.halo["n_recv"]) * ((Fr + 127) // 128 * 128) * 4)
-            kernel_path = ("tile-group SpMM on the rank's own-columns and remote-columns blocks; every rank splits only "
-                           "its own rows and fp16 planes travel, one exchange per 128-feature slice; the remote-columns "
-                           f"block is multiplied in units of {padj.slices_per_exchange} slice(s) as they land")
-            kernels_in_step = ("k_tg_amax + all_reduce(max) + k_tg_split (own rows) + exchange || [k_tg_spmm (own columns) "
-                               "+ per unit of slices: k_tg_spmm (remote columns, adds the own-columns sums) + k_tg_combine]")
-            extra["exchange_unit_slices"] = padj.slices_per_exchange
-            extra["reserved_cus_beside_exchange"] = padj._reserved_cus()
-            main_kernel = "k_tg_spmm"
-        else:
-            blk = padj.remote if (padj.last_schedule == "local-block" and padj.remote is not None) else local
-            R = lib.sgnn_rowgroup_config_for(blk.n_rows, blk.adj.nnz, extra["features_per_rank"])
-            if getattr(local, "_tg", None) and padj.last_schedule in ("none", "sliced"):
-                kernel_path = "tile-group SpMM on the rank's rows (each rank splits the gathered operand)"
-                kernels_in_step = "k_row_scale + exchange + k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine"
+        if fs is not None:
+            fadj, step, fs_build_ms = fs
+            Fw, f0s, wq = fadj.feature_slice(F)
+            step()
+            extra.update({"feature_groups": world, "row_ranks": 1, "features_per_rank": wq if wq > 0 else Fw,
+                          "adjacency_build_ms": fs_build_ms, "exchange_ranks": world,
+                          "exchange": "2 x all_to_all_single per call (rows -> feature slices -> rows)",
+                          "exchange_bytes_per_rank_per_call": 2 * world * fadj.max_rows * Fw * 4 * (world - 1) // world,
+                          "overlap": "feature-split: no exchange between hops",
+                          "collective": (f"all_to_all_single among {world} ranks, backend {dist.get_backend()} "
+                                         f"({'gloo rehearsal on one GPU' if rehearsal else 'RCCL'}), world size "
+                                         f"{dist.get_world_size()}"),
+                          "row_partition_ms_per_step": round(t_row * 1e3, 3)})
+            if len(probed) > 1:
+                extra["grid_probe_ms"] = probed
+            kernel_path, kernels_in_step, main_kernel = kernel_of(fadj.adj, extra["features_per_rank"])
+            kernel_path = (f"feature split: every rank holds the whole graph and propagates {extra['features_per_rank']} of "
+                           f"{F} columns; " + kernel_path)
+            kernels_in_step = "pack + all_to_all + " + kernels_in_step + " + all_to_all + unpack"
+            if rank == 0:
+                log(f"headline: feature split over {world} ranks; {extra['collective']}")
+            padj = None
+        if padj is not None:
+            local = padj.local            # which kernel the rank-local multiply took (decided on first use)
+            extra.update(info)
+            step()                                     # (sets padj.last_schedule for the schedule benchmarked)
+            # which schedule the timed steps run: "local-block" = own-columns block multiplied while the
+            # exchange runs, remote-columns block when it lands (with fp16 planes exchanged where the
+            # matrix-core kernel applies); "sliced" = feature slices pipelined; "none" = exchange, then multiply
+            extra["overlap"] = padj.last_schedule
+            extra["collective"] = (f"{info['exchange']} among {info['exchange_ranks']} ranks, backend "
+                                   f"{dist.get_backend()} ({'gloo rehearsal on one GPU' if rehearsal else 'RCCL'}), "
+                                   f"world size {dist.get_world_size()}")
+            if rank == 0:
+                log(f"headline: row partition over {info['exchange_ranks']} ranks, overlap {extra['overlap']}; {extra['collective']}")
+            if len(probed) > 1:
+                extra["grid_probe_ms"] = probed
+            lib = __import__("sgnn_amd._lib", fromlist=["load"]).load()
+            planes = padj.last_schedule is not None and "planes" in padj.last_schedule
+            if planes:
+                Fr = extra["features_per_rank"]
+                extra["exchange_bytes_per_rank_per_hop"] = (
+                    (padj.max_rows * padj.world if padj.halo is None else padj.halo["n_recv"]) * ((Fr + 127) // 128 * 128) * 4)
+                kernel_path = ("tile-group SpMM on the rank's own-columns and remote-columns blocks; every rank splits only "
+                               "its own rows and fp16 planes travel, one exchange per 128-feature slice; the remote-columns "
+                               f"block is multiplied in units of {padj.slices_per_exchange} slice(s) as they land")
+                kernels_in_step = ("k_tg_amax + all_reduce(max) + k_tg_split (own rows) + exchange || [k_tg_spmm (own columns) "
+                                   "+ per unit of slices: k_tg_spmm (remote columns, adds the own-columns sums) + k_tg_combine]")
+                extra["exchange_unit_slices"] = padj.slices_per_exchange
+                extra["reserved_cus_beside_exchange"] = padj._reserved_cus()
                 main_kernel = "k_tg_spmm"
             else:
-                kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
-                kernels_in_step = "k_row_scale + exchange + " + ("k_rg_spmm + k_rg_combine" if R else "k_spmm")
-                if padj.last_schedule == "local-block":
-                    kernels_in_step = ("k_row_scale + exchange || own-columns " + ("k_rg_spmm" if R else "k_spmm")
-                                       + " + remote-columns " + ("k_rg_spmm" if R else "k_spmm") + " + k_add_scale")
-                main_kernel = "k_rg_spmm" if R else "k_spmm"
+                blk = padj.remote if (padj.last_schedule == "local-block" and padj.remote is not None) else local
+                R = lib.sgnn_rowgroup_config_for(blk.n_rows, blk.adj.nnz, extra["features_per_rank"])
+                if getattr(local, "_tg", None) and padj.last_schedule in ("none", "sliced"):
+                    kernel_path = "tile-group SpMM on the rank's rows (each rank splits the gathered operand)"
+                    kernels_in_step = "k_row_scale + exchange + k_tg_amax + k_tg_split + k_tg_spmm + k_tg_combine"
+                    main_kernel = "k_tg_spmm"
+                else:
+                    kernel_path = f"row-group SpMM, R={R}" if R else "plain CSR SpMM"
+                    kernels_in_step = "k_row_scale + exchange + " + ("k_rg_spmm + k_rg_combine" if R else "k_spmm")
+                    if padj.last_schedule == "local-block":
+                        kernels_in_step = ("k_row_scale + exchange || own-columns " + ("k_rg_spmm" if R else "k_spmm")
+                                           + " + remote-columns " + ("k_rg_spmm" if R else "k_spmm") + " + k_add_scale")
+                    main_kernel = "k_rg_spmm" if R else "k_spmm"
 
     wall, ev_ms, k_ms, k_n = timed_steps(step, args.steps, args.warmup, device, world, dist if world > 1 else None)
 
@@ -673,8 +729,10 @@ def main():
                             f"nnz(A+I)={nnz}, F={F}, order={args.order}, max_degree={max_deg}, "
                             + ("unit weights" if args.weight is None else f"weight {args.weight:g} off the diagonal"),
                 "rows": "one GPU" if world == 1 else
-                        f"row partition: {extra['row_ranks']} row blocks over {world} GPUs, all-gather of the scaled "
-                        "X blocks",
+                        (f"row partition: {extra['row_ranks']} row blocks over {world} GPUs, one exchange of the "
+                         "operand's rows per hop" if extra.get("row_ranks", 1) > 1 else
+                         f"feature split: whole graph on each of {world} GPUs, {extra['features_per_rank']} columns each; "
+                         "the caller's row blocks travel by all-to-all before the first and after the last hop"),
                 "arithmetic": "fp32 in, fp32 out, fp32 accumulation; the tile-group kernel feeds the matrix cores X as "
                               "two fp16 planes (hi + lo/2048 at one power-of-two scale per feature column) that reproduce each fp32 "
                               "input to 2^-22 relative; operands they cannot represent take the plain fp32 kernel"

@@ -818,3 +818,99 @@ class _LocalBlock:
             None if a.unit_weights else _lib.ptr(a.vals), _lib.ptr(dinv_row), None,
             _lib.ptr(full), full.stride(0), _lib.ptr(out), out.stride(0), epi, _lib.ptr(ws), ws.numel(),
             _lib.current_stream(dev)))
+
+
+class FeatureSplitAdj:
+    """The other way to use P GPUs on ``A_hat^K . X``: the feature columns are independent, so
+    every rank holds the WHOLE normalised adjacency and propagates ``F / P`` of the columns, with
+    no exchange between hops at all.  A caller who owns rows of X (as with ``PartitionedAdj``:
+    ``rows`` lists them, contiguous blocks of ``ceil(n / P)``) gets there and back by two
+    all-to-alls per call -- each rank sends ``(P - 1) / P`` of its own block once in each
+    direction, ``2 . n . F . 4 / P`` bytes in all, where the row partition's all-gather receives
+    ``(P - 1) / P . n . F . 4`` per HOP (Reddit shape, 8 ranks: 123 MB per call against 491 MB per
+    hop), and an all-to-all is the pattern xGMI's point-to-point links serve best.  The price
+    is memory (every rank stores the graph and its plan: 1.3 GB on the Reddit shape) and narrower
+    multiplies (the kernels' per-stage costs do not shrink with the width: one rank's hop at 76
+    of 602 features takes 1.0 ms, not 5.3 / 8 = 0.66).  It replaces the reference's replicas
+    (main.py:39-41, model/SGNN.py:518-520), which compute everything everywhere.
+
+    Which of the two schedules is faster depends on the graph: wide features on a graph whose
+    rows share many columns (Reddit) favour this one, narrow features on a sparse graph (R-MAT
+    10 M at F = 128: 16 features per rank) the row partition.  ``bench.py --gpus N`` times both."""
+
+    def __init__(self, adj, n, rank, world, group=None):
+        self.adj, self.n, self.rank, self.world, self.group = adj, int(n), int(rank), int(world), group
+        self.max_rows = (self.n + self.world - 1) // self.world
+        lo = min(self.rank * self.max_rows, self.n)
+        hi = min(lo + self.max_rows, self.n)
+        self.rows = torch.arange(lo, hi, dtype=torch.int64)
+        self.n_local = hi - lo
+        self.global_nnz = adj.nnz if hasattr(adj, "nnz") else None
+        self.last_schedule = None
+        self._bufs = {}
+
+    @classmethod
+    def from_coo(cls, row, col, val, n, device, rank, world, group=None, adj_factory=None):
+        """Every rank passes the same COO.  ``adj_factory(row, col, val, n)`` is a test hook that
+        builds the object whose ``propagate(X, order)`` is the one-GPU product (default: the
+        device adjacency through the C ABI)."""
+        if adj_factory is not None:
+            adj = adj_factory(row, col, val, n)
+        else:
+            adj = NormAdj.from_coo(torch.as_tensor(row).to(device), torch.as_tensor(col).to(device),
+                                   None if val is None else torch.as_tensor(val).to(device), n, device)
+        return cls(adj, n, rank, world, group)
+
+    def feature_slice(self, F):
+        """``(width of a slice, first feature of this rank's slice, its width)``: equal slices of
+        ``ceil(F / P)`` features rounded up to a multiple of 4 (16-byte rows); the last ranks'
+        slices may be short or empty."""
+        Fw = ((F + self.world - 1) // self.world + 3) // 4 * 4
+        f0 = min(self.rank * Fw, F)
+        return Fw, f0, min(Fw, F - f0)
+
+    def _all_to_all(self, recv, send):
+        if self.world == 1:
+            recv.copy_(send)
+            return
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":          # tests: several ranks on one GPU
+            host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(host.view(-1), send.cpu().view(-1), group=self.group)
+            recv.copy_(host)
+            return
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+
+    def propagate(self, X_local, order=1):
+        """``A_hat^order . X`` for this rank's rows (``X_local`` = rows ``self.rows`` of X)."""
+        order = int(order)
+        if order <= 0:
+            return X_local
+        if X_local.shape[0] != self.n_local:
+            raise ValueError(f"rank {self.rank} owns {self.n_local} rows, got {X_local.shape[0]}")
+        P, m, F = self.world, self.max_rows, X_local.shape[1]
+        Fw, f0, wq = self.feature_slice(F)
+        dev, dt = X_local.device, X_local.dtype
+        key = (F, dev, dt)
+        b = self._bufs.get(key)
+        if b is None:
+            # [P, m, Fw] blocks: block q of `send` goes to rank q; padding rows / features stay zero
+            b = _keep(self._bufs, key, [torch.zeros((P, m, Fw), dtype=dt, device=dev) for _ in range(4)])
+        send, recv, back, out_blocks = b
+        nl = self.n_local
+        for q in range(P):                       # my rows, cut by feature slice
+            w = min(Fw, max(F - q * Fw, 0))
+            if w > 0 and nl > 0:
+                send[q, :nl, :w].copy_(X_local[:, q * Fw:q * Fw + w])
+        self._all_to_all(recv, send)             # recv[p] = rank p's rows x my features: all rows, in order
+        XF = recv.view(P * m, Fw)
+        if wq > 0:
+            YF = self.adj.propagate(XF[:self.n, :wq], order)
+            back.view(P * m, Fw)[:self.n, :wq].copy_(YF)
+        self._all_to_all(out_blocks, back)       # out_blocks[q] = my rows x slice q
+        out = torch.empty((nl, F), dtype=dt, device=dev)
+        for q in range(P):
+            w = min(Fw, max(F - q * Fw, 0))
+            if w > 0 and nl > 0:
+                out[:, q * Fw:q * Fw + w].copy_(out_blocks[q, :nl, :w])
+        self.last_schedule = "feature-split"
+        return out

@@ -240,3 +240,67 @@ def test_degree_cyclic_deal_balances_rows_and_entries():
         sizes = [order[p::world].size for p in range(world)]
         assert max(sizes) - min(sizes) <= 1
         assert max(loads) - min(loads) <= counts.max()          # within one row's entries of each other
+
+
+class _OracleWhole:
+    """CPU stand-in for the whole-graph device adjacency of the feature-split schedule."""
+
+    def __init__(self, row, col, val, n):
+        import scipy.sparse as sp
+        r, c = np.asarray(row), np.asarray(col)
+        v = np.ones(r.size, np.float32) if val is None else np.asarray(val, np.float32)
+        self.A = sp.coo_matrix((v, (r, c)), shape=(n, n))
+        self.nnz = int(r.size) + n
+
+    def propagate(self, X, order):
+        return torch.from_numpy(orc.propagate_scipy(self.A, X.numpy().copy(), order))
+
+
+def _feature_worker(rank, world, port, n, r, c, X, order, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgnn_amd.dist import FeatureSplitAdj
+        fadj = FeatureSplitAdj.from_coo(r, c, None, n, "cpu", rank, world, adj_factory=_OracleWhole)
+        rows = fadj.rows.numpy()
+        Y = fadj.propagate(torch.from_numpy(X[rows].copy()), order)
+        Y2 = fadj.propagate(torch.from_numpy(X[rows].copy()), order)      # buffers are reused: same result
+        assert torch.equal(Y, Y2) and fadj.last_schedule == "feature-split"
+        q.put((rank, rows, Y.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,order,n,F", [(2, 1, 700, 12), (3, 2, 701, 10), (4, 3, 699, 7), (8, 2, 700, 5)])
+def test_feature_split_matches_single(world, order, n, F):
+    """Every rank holds the whole graph and propagates its slice of the feature columns; a
+    caller who owns rows gets there and back by two all-to-alls.  Uneven blocks (n not a
+    multiple of the world size), slices that come out short, and ranks whose slice is empty
+    (8 ranks, 5 features in slices of 4: ranks 2..7 multiply nothing)."""
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    r, c = symmetric_simple_numpy(n, 4000, seed=5)
+    X = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
+    exp = orc.propagate_scipy(__import__("scipy.sparse").sparse.coo_matrix(
+        (np.ones(r.size, np.float32), (r, c)), shape=(n, n)), X, order)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_feature_worker, args=(k, world, port, n, r, c, X, order, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Y = np.zeros_like(exp)
+    covered = np.zeros(n, bool)
+    for rank, rows, y in got:
+        assert not covered[rows].any()
+        covered[rows] = True
+        Y[rows] = y
+    assert covered.all()
+    # columns are independent and every column is propagated whole on one rank: the oracle's
+    # arithmetic on a column slice is the oracle's arithmetic on the whole matrix
+    assert np.array_equal(Y, exp)

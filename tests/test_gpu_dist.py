@@ -77,11 +77,11 @@ def test_two_ranks_one_gpu_match_single(gpu_device, F, order, slices, w, exchang
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
 
 
-def _run_ranks(world, args_of):
+def _run_ranks(world, args_of, target=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=args_of(k, port, q)) for k in range(world)]
+    procs = [ctx.Process(target=target or _worker, args=args_of(k, port, q)) for k in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
@@ -321,3 +321,51 @@ def test_four_ranks_two_by_two_grid_on_one_gpu(gpu_device, slices):
         hits[np.ix_(rows, np.arange(f0, f1))] += 1
     assert (hits == 1).all()
     assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
+
+
+def _feature_worker(rank, world, port, n, r, c, X, order, q, w):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgnn_amd.dist import FeatureSplitAdj
+        dev = torch.device("cuda:0")
+        val = None if w is None else torch.full((r.size,), w, dtype=torch.float32)
+        fadj = FeatureSplitAdj.from_coo(torch.from_numpy(r), torch.from_numpy(c), val, n, dev, rank, world)
+        rows = fadj.rows.numpy()
+        Xl = torch.from_numpy(X[rows].copy()).to(dev)
+        Y = fadj.propagate(Xl, order)
+        Y2 = fadj.propagate(Xl, order)
+        torch.cuda.synchronize()
+        assert torch.equal(Y, Y2)
+        q.put((rank, rows, Y.cpu().numpy(), fadj.last_schedule))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,order,w", [(2, 602, 2, None), (4, 130, 1, 2.0), (4, 41, 3, None)])
+def test_feature_split_on_one_gpu_matches_single(gpu_device, world, F, order, w):
+    """The feature-split schedule with the real kernels, ranks sharing cuda:0: every rank holds the
+    whole graph (dense enough here for the matrix-core kernel at the wider slices) and propagates
+    F / world columns; two all-to-alls carry the caller's rows there and back."""
+    from sgnn_amd import NormAdj
+    from sgnn_amd.graphgen import symmetric_simple_numpy
+    n = 16_001                                             # blocks of unequal size
+    r, c = symmetric_simple_numpy(n, 400_000, seed=17)
+    X = np.random.default_rng(6).standard_normal((n, F)).astype(np.float32)
+    adj = NormAdj.from_coo(r, c, None if w is None else np.full(r.size, w, np.float32), n, gpu_device)
+    adj.use_tilegroup, adj.use_rowgroup = False, False
+    Xd = torch.from_numpy(X).to(gpu_device)
+    exp = adj.propagate(Xd, order).cpu().numpy()
+    scale = adj.propagate(Xd.abs(), order).cpu().numpy()
+    got = _run_ranks(world, lambda k, port, q: (k, world, port, n, r, c, X, order, q, w), target=_feature_worker)
+    Y = np.zeros_like(exp)
+    seen = np.zeros(n, bool)
+    for rank, rows, y, sched in got:
+        assert sched == "feature-split" and not seen[rows].any()
+        seen[rows] = True
+        Y[rows] = y
+    assert seen.all()
+    assert np.linalg.norm(Y - exp) / np.linalg.norm(exp) <= 1e-5
+    assert float((np.abs(Y - exp) / np.maximum(scale, 1e-30)).max()) <= 1e-5
