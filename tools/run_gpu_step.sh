@@ -1,10 +1,10 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-export SGNN_BENCH_REHEARSAL=1
-timeout -k 10 800 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 4 --steps 5 --warmup 2 > gpurun_out/r03_rehearsal4.json 2> gpurun_out/r03_rehearsal4.err || { tail -30 gpurun_out/r03_rehearsal4.err; exit 1; }
-grep "\[bench\]" gpurun_out/r03_rehearsal4.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r03_rehearsal4.json').read().strip().splitlines()[-1])
-print(json.dumps(d['config'])[:1800]); print({k:v for k,v in d['roofline'].items() if k!='kernels_in_step'}); print(d['value'], d['ms_per_step'])
-PY
+run() { tag=$1; shift; bash tools/profile_gpu.sh $tag k_tg_spmm "$@" > gpurun_out/p_$tag.log 2>&1 || { tail -20 gpurun_out/p_$tag.log; exit 1; }; echo "$tag done"; }
+run r03_reddit_f602_tilegroup
+run r03_reddit_w2_tilegroup --weight 2
+run r03_reddit_clip22000_tilegroup --max-degree 22000
+run r03_reddit_order2_tilegroup --order 2
+run r03_reddit128_tilegroup --workload reddit128
+run r03_products_tilegroup --workload products
+run r03_rmat10m_tilegroup --workload rmat10m
