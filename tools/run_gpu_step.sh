@@ -1,10 +1,5 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-run() { tag=$1; shift; bash tools/profile_gpu.sh $tag k_tg_spmm "$@" > gpurun_out/p_$tag.log 2>&1 || { tail -20 gpurun_out/p_$tag.log; exit 1; }; echo "$tag done"; }
-run r03_reddit_f602_tilegroup
-run r03_reddit_w2_tilegroup --weight 2
-run r03_reddit_clip22000_tilegroup --max-degree 22000
-run r03_reddit_order2_tilegroup --order 2
-run r03_reddit128_tilegroup --workload reddit128
-run r03_products_tilegroup --workload products
-run r03_rmat10m_tilegroup --workload rmat10m
+timeout -k 10 300 python -u tools/sgc_epoch.py pubmed reddit > gpurun_out/r03_sgc_epoch.jsonl 2> gpurun_out/r03_sgc.err || { tail -n 5 gpurun_out/r03_sgc.err; exit 1; }
+timeout -k 10 300 python -u tools/gcn_epoch.py pubmed reddit > gpurun_out/r03_gcn_epoch.jsonl 2> gpurun_out/r03_gcn.err || { tail -n 5 gpurun_out/r03_gcn.err; exit 1; }
+cat gpurun_out/r03_sgc_epoch.jsonl gpurun_out/r03_gcn_epoch.jsonl | cut -c1-300
