@@ -1,5 +1,4 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -u tools/sgc_epoch.py pubmed reddit > gpurun_out/r03_sgc_epoch.jsonl 2> gpurun_out/r03_sgc.err || { tail -n 5 gpurun_out/r03_sgc.err; exit 1; }
-timeout -k 10 300 python -u tools/gcn_epoch.py pubmed reddit > gpurun_out/r03_gcn_epoch.jsonl 2> gpurun_out/r03_gcn.err || { tail -n 5 gpurun_out/r03_gcn.err; exit 1; }
-cat gpurun_out/r03_sgc_epoch.jsonl gpurun_out/r03_gcn_epoch.jsonl | cut -c1-300
+timeout -k 10 500 python -u -m pytest tests/test_gpu_tilegroup.py -x -q --timeout 120 --timeout-method thread > gpurun_out/t_tg.log 2>&1; rc=$?; tail -n 2 gpurun_out/t_tg.log; [ $rc -eq 0 ] || { grep -E "^E |FAILED" gpurun_out/t_tg.log | head; exit 1; }
+for v in ab_old.so sgnn_amd/libsgnn_hip.so ab_old.so sgnn_amd/libsgnn_hip.so; do timeout -k 10 200 python -u tools/ab_narrow.py $v 16 41 64 2>&1 | grep -v amdgpu.ids || exit 1; done
