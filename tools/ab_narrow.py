@@ -20,6 +20,8 @@ row, col = rmat_undirected_device(n, E, seed=1, device=dev)
 adj = NormAdj.from_coo(row, col, None, n, dev)
 del row, col
 lib = _lib.load()
+if os.environ.get("TG_SEG"):          # stages per work item of the plan built below (0 / unset: the library's choice)
+    lib.sgnn_tune_set(b"tg_seg", int(os.environ["TG_SEG"]))
 for F in [int(v) for v in sys.argv[2:]] or [16, 32, 41, 64, 76, 96, 128]:
     X = torch.randn(n, F, device=dev)
     adj.use_tilegroup = True
@@ -37,5 +39,5 @@ for F in [int(v) for v in sys.argv[2:]] or [16, 32, 41, 64, 76, 96, 128]:
     lib.sgnn_tune_set(b"time_kernel", 0)
     adj.use_tilegroup = False
     Yr = adj.propagate(X, 1)
-    print(f"{sys.argv[1]} F={F}: hop {e0.elapsed_time(e1) / 20:.3f} ms, main kernel {k_ms / k_n:.3f} ms, "
+    print(f"{sys.argv[1]} seg={os.environ.get('TG_SEG', 'auto')} items={adj._tg['items']} F={F}: hop {e0.elapsed_time(e1) / 20:.3f} ms, main kernel {k_ms / k_n:.3f} ms, "
           f"normwise difference from the other kernels {float((Y - Yr).norm() / Yr.norm()):.2e}", flush=True)
