@@ -858,6 +858,25 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   // of columns 16 g1 + 4 p .. + 3 of the row whose k index is 8 h + 4 r + q (read r = 0, 1)
   const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
   const uint32_t lane_off = uint32_t(32 * g1 + 8 * p);
+  // Narrow slices (one or two N-tiles) fetch fuller instructions: a DMA instruction's 64 lanes
+  // carry the hi (or lo) segments of 16 / NT rows instead of the NT live segments of 4 rows
+  // -- 2 NT row instructions per wavefront and stage instead of 8 -- and the rows lie in LDS
+  // in blocks of 16 / NT rows, 2 KB each: hi segment s of row r at s * (1024 / NT) + r * 64, the
+  // lo segments 1 KB behind.  Rows whose slots differ in their low two bits still sit in
+  // different bank quarters.  (What a narrow stage costs is mostly its instructions: see the
+  // ablation in the kernel's design notes.)
+  constexpr bool kPacked = NT <= 2 && kIssuers == 8;
+  constexpr int kPackRows = kPacked ? 16 / NT : 4;            // rows per row instruction
+  constexpr int kPackInstr = kPacked ? 2 * NT : kRowInstr;    // row instructions per wavefront and stage
+  constexpr int kPackCols = kPacked ? NT : kColRegs;          // column ids a lane holds for them
+  constexpr uint32_t kSegStride = kPacked ? 1024u / NT : 256u;
+  constexpr uint32_t kLoBase = kPacked ? 1024u : 4u * 256u;
+  // the plan's row offsets (slot / 4 * 2 KB + slot % 4 * 64) in the packed layout: slot / R * 2 KB + slot % R * 64, R = 16 / NT
+  auto packed = [&](uint32_t d) -> uint32_t {
+    if constexpr (!kPacked) return d;
+    else if constexpr (NT == 2) return ((d >> 1) & 0x78007800u) | ((d >> 3) & 0x01000100u) | (d & 0x00FF00FFu);
+    else return ((d >> 2) & 0x38003800u) | ((d >> 3) & 0x03000300u) | (d & 0x00FF00FFu);
+  };
   const uint32_t offs_off = uint32_t(kStageRowsBytes + 4 * (4 * h + q));   // this lane's dword of a step's offsets (r = 0 | r = 1 << 16)
   const uint32_t bits_off = uint32_t(kStageRowsBytes + kSlotsBytes + 2 * (lane & 31) + h);
   // A row of a stage is 512 bytes: eight 64-byte segments, hi N-tiles 0..3 then lo N-tiles 0..3.
@@ -868,6 +887,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   // instruction brings the hi half of a block, the next its lo half; lane l writes bytes
   // 16 l .. 16 l + 15 of that kilobyte: segment l >> 4, row (l >> 2) & 3.
   const uint32_t dma_row = uint32_t(lane >> 2) & 3u;
+  const uint32_t pack_row = uint32_t(lane >> 2) & uint32_t(kPackRows - 1);   // packed instructions: the lane's row of the block
   const uint32_t src_off = (uint32_t(lane >> 4) << 6) | (uint32_t(lane & 3) << 4);   // inside the node's hi (or lo) 256 bytes
   const bool small = a.slice_bytes < (int64_t(1) << 32);   // row offsets fit 32 bits
 
@@ -880,6 +900,22 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   auto issue_rows = [&](int s, const int (&col)[kColRegs], auto lo_tag, auto hi_tag) {   // row instructions lo .. hi - 1 of the wavefront's kRowInstr
     constexpr int lo = decltype(lo_tag)::value, hi = decltype(hi_tag)::value;
     const uint32_t buf = lds0 + kTableBytes + uint32_t((s - s0) & (kRing - 1)) * kStageBytes;
+    if constexpr (kPacked) {
+      // instruction i: block i >> 1 of the wavefront's 16 / kPackRows, hi (even) or lo (odd) half
+      if (!(a.mode & 2)) {
+        const uint32_t seg_src = NT == 2 ? (uint32_t(lane >> 5) << 6) : 0u;   // which N-tile of the row this lane moves
+#pragma unroll
+        for (int i = 0; i < kPackInstr; ++i) {
+          if (i < lo || i >= hi) continue;
+          const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + uint32_t(w * (16 / kPackRows) + (i >> 1)) * 2048u + uint32_t(i & 1) * 1024u);
+          const uint32_t off = seg_src + (uint32_t(lane & 3) << 4) + uint32_t(i & 1) * 256u;
+          const int c = (a.mode & 64) ? (col[i >> 1] & ((a.mode & 512) ? 511 : 4095)) : col[i >> 1];
+          if (small) tg_dma16_off(xs, (uint32_t(c) << 9) | off, dst);
+          else tg_dma16(xs + int64_t(c) * kRowBytes + off, dst);
+        }
+      }
+      return;
+    }
     // (lanes whose N-tile holds no feature below F fetch nothing: lane l moves segment l >> 4)
     if (!(a.mode & 2) && (lane >> 4) < NT && w < kIssuers) {
 #pragma unroll
@@ -959,9 +995,14 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
   // stage can be asked for as soon as its barrier has fallen.
   int cur_sf = 0, cur_h0 = 0, cur_h1 = 0, cur_h2 = 0;
   if (ns > 0) {   // the item's first stage: ids and step counts from global memory
-    int col[kColRegs];
+    int col[kColRegs] = {};
+    if constexpr (kPacked) {
 #pragma unroll
-    for (int b = 0; b < kColRegs; ++b) col[b] = a.stage_col[int64_t(s0) * kStageCols + kIssuerRows * (w & (kIssuers - 1)) + 4 * b + dma_row];
+      for (int b = 0; b < kPackCols; ++b) col[b] = a.stage_col[int64_t(s0) * kStageCols + 16 * w + kPackRows * b + pack_row];
+    } else {
+#pragma unroll
+      for (int b = 0; b < kColRegs; ++b) col[b] = a.stage_col[int64_t(s0) * kStageCols + kIssuerRows * (w & (kIssuers - 1)) + 4 * b + dma_row];
+    }
     const int32_t* st0 = a.step0 + int64_t(s0) * kSubs;
     cur_sf = __builtin_amdgcn_readfirstlane(st0[0]);
     cur_h0 = __builtin_amdgcn_readfirstlane(st0[2 * w]);
@@ -1004,9 +1045,9 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
       return u32x4{x[0], x[1], y[0], y[1]};
     };
     auto pattern_lo = [&](const u32x4& hi) { return hi & 0x10001000u; };
-    auto read_tile = [&](uint32_t base_a, uint32_t base_b, int seg) {   // seg: 0..3 = hi N-tiles, 4..7 = lo
-      const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_a + uint32_t(seg * 256)));
-      const hv4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_b + uint32_t(seg * 256)));
+    auto read_tile = [&](uint32_t base_a, uint32_t base_b, uint32_t seg_off) {   // seg_off: where the N-tile's hi or lo segment lies in a block of rows
+      const hv4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_a + seg_off));
+      const hv4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(lds<hv4>(base_b + seg_off));
       h8 r;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -1031,9 +1072,15 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     int col[kColRegs] = {};
     int nsf = 0, nsf2 = 0, nh0 = 0, nh1 = 0, nh2 = 0;
     if (more) {
-      const int* nc = hdr + kHdrBytes / 4 + kIssuerRows * (w & (kIssuers - 1)) + dma_row;
+      if constexpr (kPacked) {
+        const int* nc = hdr + kHdrBytes / 4 + 16 * w + pack_row;
 #pragma unroll
-      for (int b = 0; b < kColRegs; ++b) col[b] = nc[4 * b];
+        for (int b = 0; b < kPackCols; ++b) col[b] = nc[kPackRows * b];
+      } else {
+        const int* nc = hdr + kHdrBytes / 4 + kIssuerRows * (w & (kIssuers - 1)) + dma_row;
+#pragma unroll
+        for (int b = 0; b < kColRegs; ++b) col[b] = nc[4 * b];
+      }
       nsf = hdr[kSubs];
       nsf2 = hdr[2 * kSubs];
       nh0 = hdr[kSubs + 2 * w];
@@ -1053,12 +1100,13 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
     if (more) issue_rows(s0 + k + 1, col, std::integral_constant<int, 0>{}, std::integral_constant<int, kEarlyRows>{});
     if (steps_on) {
       ahi = pattern_hi((bt & 15u) << 3, (bt >> 1) & 0x78u);
-      base_a = stage_lane + (offs & 0xFFFFu);
-      base_b = stage_lane + (offs >> 16);
+      const uint32_t op = packed(offs);
+      base_a = stage_lane + (op & 0xFFFFu);
+      base_b = stage_lane + (op >> 16);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, nt);
+      for (int nt = 0; nt < NT; ++nt) bh[nt] = read_tile(base_a, base_b, uint32_t(nt) * kSegStride);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, 4 + nt);
+      for (int nt = 0; nt < NT; ++nt) bl[nt] = read_tile(base_a, base_b, kLoBase + uint32_t(nt) * kSegStride);
       record(offs, bt);
     }
     // The next stage is issued from the ids this stage's image carries, by every wavefront
@@ -1086,8 +1134,9 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
       alo = pattern_lo(ahi);
       auto body = [&](auto tt_tag) {
         constexpr int TT = decltype(tt_tag)::value;
-        base_a = stage_lane + (offs & 0xFFFFu);
-        base_b = stage_lane + (offs >> 16);
+        const uint32_t op = packed(offs);
+        base_a = stage_lane + (op & 0xFFFFu);
+        base_b = stage_lane + (op >> 16);
         ta = (bt & 15u) << 3;
         tb = (bt >> 1) & 0x78u;
         record(offs, bt);
@@ -1096,7 +1145,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
         for (int nt = 0; nt < NT; ++nt) {
           acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), bh[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          bh[nt] = read_tile(base_a, base_b, nt);
+          bh[nt] = read_tile(base_a, base_b, uint32_t(nt) * kSegStride);
           if (nt == NT - 1) ahi = pattern_hi(ta, tb);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1104,7 +1153,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
         for (int nt = 0; nt < NT; ++nt) {
           acc[TT][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), bl[nt], acc[TT][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          bl[nt] = read_tile(base_a, base_b, 4 + nt);
+          bl[nt] = read_tile(base_a, base_b, kLoBase + uint32_t(nt) * kSegStride);
           if (nt == NT - 1) alo = pattern_lo(ahi);
           __builtin_amdgcn_sched_barrier(0);
         }
