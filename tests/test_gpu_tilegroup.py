@@ -303,7 +303,7 @@ def test_slice_ranges_equal_the_whole_launch_bit_for_bit(gpu_device, weight, to_
                                             _lib.ptr(state), st))
     corr = getattr(adj, "corr", None)
 
-    def run(ranges):
+    def run(ranges, reserve=0):
         Y = torch.zeros(n, F, device=gpu_device)
         out_planes = torch.zeros(pl_bytes, dtype=torch.uint8, device=gpu_device) if to_planes else None
         out_state = torch.full((sb // 4,), -1, dtype=torch.int32, device=gpu_device) if to_planes else None
@@ -315,7 +315,7 @@ def test_slice_ranges_equal_the_whole_launch_bit_for_bit(gpu_device, weight, to_
                 _lib.EPI_SCALE_ROW2 if to_planes else _lib.EPI_SCALE_ROW, _lib.ptr(ws), ws.numel(), adj.nnz,
                 None, None, None, _lib.ptr(adj.dinv), _lib.ptr(X), F, None, 0, 0, None, 0,
                 _lib.ptr(out_planes) if to_planes else None, n, 0, _lib.ptr(out_state) if to_planes else None, 1,
-                s0, cnt, 0, st))
+                s0, cnt, reserve, st))
         torch.cuda.synchronize()
         assert int(state[_lib.TG_STATE_FLAG].item()) == 0
         if to_planes:
@@ -329,7 +329,11 @@ def test_slice_ranges_equal_the_whole_launch_bit_for_bit(gpu_device, weight, to_
     whole, whole_state = run([(0, 0)])
     parts, parts_state = run([(0, 2), (2, 1), (3, 2)])
     assert torch.equal(whole, parts)
+    # CUs left free for a collective's kernels: fewer workgroups take the same units off the counter
+    spared, spared_state = run([(0, 2), (2, 1), (3, 2)], reserve=32)
+    assert torch.equal(whole, spared)
     if to_planes:
+        assert torch.equal(whole_state, spared_state)
         assert torch.equal(whole_state, parts_state)
         assert int(whole_state[_lib.TG_STATE_FLAG].item()) == 0
     # a range that is not the whole operand has no fall-back of its own, and ranges must lie inside the operand
