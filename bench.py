@@ -548,13 +548,20 @@ def main():
         # call carry the rows there and back).
         t_row, step, info = probe_grid(1, probed)
         fs = None
+        fs_ok = torch.ones(1, device=device)
         if not args.no_feature_split:
             from sgnn_amd.dist import FeatureSplitAdj
             t0 = time.perf_counter()
-            fadj = FeatureSplitAdj.from_coo(row, col, None, n, device, rank, world)
-            torch.cuda.synchronize()
+            try:                                  # (a rank that cannot hold the whole graph takes every rank out of this schedule)
+                fadj = FeatureSplitAdj.from_coo(row, col, None, n, device, rank, world)
+                torch.cuda.synchronize()
+                Xf = X[fadj.rows.to(device)].contiguous()
+            except Exception as exc:              # noqa: BLE001
+                print(f"[rank {rank}] feature split not built: {exc}", file=sys.stderr, flush=True)
+                fs_ok.zero_()
+            dist.all_reduce(fs_ok, op=dist.ReduceOp.MIN)
+        if not args.no_feature_split and fs_ok.item() != 0:
             fs_build_ms = (time.perf_counter() - t0) * 1e3
-            Xf = X[fadj.rows.to(device)].contiguous()
             fs_step = lambda: fadj.propagate(Xf, args.order)      # noqa: E731
             t_fs = probe(fs_step)
             probed["feature-split"] = round(t_fs * 1e3, 3)
