@@ -61,7 +61,8 @@ int sgnn_version(void);
  * items are ordered by (all three affect plans built afterwards), "tg_seg" = stages per
  * tile-group work item, "tg_order" = order of the tile-group work items (0: chosen by the
  * graph, the default; 1: longest first; -1: neighbours together; > 1: by column blocks of
- * this width), "tg_mode" = diagnostic switches of the tile-group kernel,
+ * this width), "tg_combine_gy" = workgroups per split group of the tile-group combine pass,
+ * "tg_mode" = diagnostic switches of the tile-group kernel,
  * "time_kernel" = 1/0 turns the kernel timer on/off (see sgnn_kernel_time_ms); value 0
  * restores the built-in policy.  No reference counterpart. */
 int sgnn_tune_set(const char* key, int value);

@@ -86,6 +86,7 @@ static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned s
 static_assert(kTableBytes + kWaves * (kStageOutBytes + kRowTabBytes) <= kLdsBytes, "the write-out staging must fit the ring");
 
 std::atomic<int> g_seg_stages{0};     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
+std::atomic<int> g_combine_gy{0};     // workgroups per split group of the combine pass (sgnn_tune_set("tg_combine_gy", v)); 0 = the built-in choice
 std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_order", v)): 0 = chosen by the graph; 1 = longest first; < 0 = neighbours together (length buckets, then column block, then group); > 1 = by column blocks of this width
 std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only (results are then wrong); 128 = one workgroup per unit, 256 / 1024 = one work counter per XCD / one for the launch whatever the plan says
 
@@ -1703,6 +1704,7 @@ namespace sgnn {
 void set_tilegroup_mode(int m) { g_tg_mode = m; }
 void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 0; }
 void set_tilegroup_order(int cols) { g_order_cols = cols; }
+void set_tilegroup_combine_rows(int gy) { g_combine_gy = gy; }
 }  // namespace sgnn
 
 extern "C" {
@@ -2039,7 +2041,8 @@ int sgnn_spmm_tilegroup_slices_f32(int64_t n_rows, int64_t n_cols, int64_t F, co
     const int quads = tg_combine_quads(a.F, a.Fpad, planes_out != nullptr);
     // 64 workgroups per split group where there are few groups, fewer where there are thousands
     // (every workgroup ends in one atomic per feature when it writes planes)
-    const unsigned gy = unsigned(long_groups >= 16384 ? 1 : (16384 / long_groups > 64 ? 64 : 16384 / long_groups));
+    unsigned gy = unsigned(long_groups >= 16384 ? 1 : (16384 / long_groups > 64 ? 64 : 16384 / long_groups));
+    if (g_combine_gy.load() > 0) gy = unsigned(g_combine_gy.load());
     hipLaunchKernelGGL(k_tg_combine, dim3(unsigned(long_groups), gy), dim3(tg_combine_threads(quads)), 0, st, a);
     HIP_TRY(hipGetLastError());
   }

@@ -1,3 +1,3 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-for v in ab_old.so sgnn_amd/libsgnn_hip.so ab_old.so sgnn_amd/libsgnn_hip.so; do timeout -k 10 200 python -u tools/ab_lib.py $v 2>&1 | grep -v amdgpu.ids | cut -c1-120 || exit 1; done
+timeout -k 10 300 python -u tools/combine_probe.py 0,8,16,32,64,128,0,16,32 2>&1 | grep -v amdgpu.ids
