@@ -232,7 +232,16 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           (>= n: the n rows may be part of a larger operand, a rank's rows
  *                           of a partitioned matrix, whose ranks have agreed on the maxima
  *                           in between); `operand_rows` sizes the limit of tiny elements
- *   sgnn_tilegroup_split_f32  both, for an operand that is split whole
+ *   sgnn_tilegroup_split_f32  both, for an operand that is split whole.  From 65536 rows on the
+ *                           scales are provisional: the maxima of every 32nd row, times 8,
+ *                           stand in for the maxima of all rows (one pass over the operand
+ *                           less); the split tests every element against its bound, and one
+ *                           beyond it (an outlier the sample missed) makes the exact passes,
+ *                           launched behind the provisional ones in any case, run instead of
+ *                           returning at once (third word of the state: they ran; fourth: the
+ *                           maxima are a sample's).  The bound of a feature then lies between
+ *                           half and eight times its largest magnitude.
+ *                           sgnn_tune_set("tg_no_sample", 1) switches the sampling off
  *   sgnn_spmm_tilegroup_f32   Y = diag(dinv_row) . (w_off * (pattern . planes + addend) + diag(corr) . x'),
  *                           epilogue as sgnn_spmm_csr_f32.  corr (nullable) = stored diagonal
  *                           value - w_off per row: the loaders' A + A^T carries 2.0 off the

@@ -597,6 +597,7 @@ int sgnn_tune_set(const char* key, int value) {
   else if (!std::strcmp(key, "tg_mode")) sgnn::set_tilegroup_mode(value);
   else if (!std::strcmp(key, "tg_order")) sgnn::set_tilegroup_order(value);
   else if (!std::strcmp(key, "tg_combine_gy")) sgnn::set_tilegroup_combine_rows(value);
+  else if (!std::strcmp(key, "tg_no_sample")) sgnn::set_tilegroup_no_sample(value);
   else if (!std::strcmp(key, "time_kernel")) {
     std::lock_guard<std::mutex> lock(sgnn::g_timer_mu);
     sgnn::g_timer_on = value != 0;

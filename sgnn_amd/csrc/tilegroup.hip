@@ -86,6 +86,7 @@ static_assert(kStageBytes % 512 == 0, "the slot swizzle needs 512-byte aligned s
 static_assert(kTableBytes + kWaves * (kStageOutBytes + kRowTabBytes) <= kLdsBytes, "the write-out staging must fit the ring");
 
 std::atomic<int> g_seg_stages{0};     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
+std::atomic<int> g_no_sample{0};      // sgnn_tune_set("tg_no_sample", 1): the split pass always measures the maxima of all rows first
 std::atomic<int> g_combine_gy{0};     // workgroups per split group of the combine pass (sgnn_tune_set("tg_combine_gy", v)); 0 = the built-in choice
 std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_order", v)): 0 = chosen by the graph; 1 = longest first; < 0 = neighbours together (length buckets, then column block, then group); > 1 = by column blocks of this width
 std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only (results are then wrong); 128 = one workgroup per unit, 256 / 1024 = one work counter per XCD / one for the launch whatever the plan says
@@ -93,7 +94,8 @@ std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", 
 struct TgState {          // device words that carry an operand's scales and its fall-back flag to the SpMM that reads it
   uint32_t amax_all;      // bit pattern of the largest |element| over all features (diagnostics)
   uint32_t flag;          // != 0: the operand cannot go through the fp16 planes (1: an element, 2: too many tiny ones, 4: plan mismatch, 8: inherited from the hop before)
-  uint32_t rsv[2];
+  uint32_t redo;          // the split pass met an element its sampled bound cannot hold: the exact passes behind it run
+  uint32_t sampled;       // the maxima are those of a sample of the rows (the bounds carry a margin): not a bound for the next operand
   uint32_t tiny;          // nonzero elements that keep fewer than 17 of their bits in the planes
   uint32_t rsv2;
   uint32_t tiny_limit;    // more tiny elements than this: fall back
@@ -524,7 +526,11 @@ __global__ void k_tg_item_place(int64_t items, const uint64_t* __restrict__ keys
 // ones per thread; rows are walked four at a time so that four loads are in flight per lane; a
 // narrow row leaves room for several row quadruples side by side (`subs`), folded through LDS.
 __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, int Fpad, const float* __restrict__ scale_row,
-                                                 const float* __restrict__ X, int64_t ldx, TgState* __restrict__ state) {
+                                                 const float* __restrict__ X, int64_t ldx, TgState* __restrict__ state,
+                                                 int64_t rstep, int only_redo) {
+  // n rows, every rstep-th of the operand (a sample gives the split pass its provisional scales);
+  // only_redo: the exact pass behind a split that met an element beyond them -- nothing to do otherwise
+  if (only_redo && state->redo == 0) return;
   __shared__ uint32_t smax[2048];
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
   const int V = pairs ? 2 : 1;
@@ -541,10 +547,10 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, int Fpad
         float2 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          sr[i] = (r0 + i < n) ? (scale_row ? scale_row[r0 + i] : 1.0f) : 0.0f;
+          sr[i] = (r0 + i < n) ? (scale_row ? scale_row[(r0 + i) * rstep] : 1.0f) : 0.0f;
           v[i] = float2{0.0f, 0.0f};
           if (r0 + i < n) {
-            const float* row = X + (r0 + i) * ldx;
+            const float* row = X + (r0 + i) * rstep * ldx;
             if (pairs && f + 1 < F) v[i] = *reinterpret_cast<const float2*>(row + f);
             else v[i].x = row[f];
           }
@@ -588,7 +594,8 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, int Fpad
 
 // the workgroups' maxima folded per feature: a workgroup takes 64 features, its 16 wavefronts
 // every 16th workgroup's row of the scratch (lanes along the features, several loads in flight)
-__global__ __launch_bounds__(1024) void k_tg_amax_fold(int F, int Fpad, int blocks, TgState* __restrict__ state) {
+__global__ __launch_bounds__(1024) void k_tg_amax_fold(int F, int Fpad, int blocks, TgState* __restrict__ state, int only_redo) {
+  if (only_redo && state->redo == 0) return;
   __shared__ uint32_t part[16][64];
   const int fx = threadIdx.x & 63, by = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + fx;
@@ -659,10 +666,19 @@ __device__ __forceinline__ bool tg_beyond(uint32_t max_bits, uint32_t bound_bits
 __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t n_slices,
                                                   const float* __restrict__ scale_row, const float* __restrict__ X,
                                                   int64_t ldx, char* __restrict__ planes, int64_t slice_stride,
-                                                  TgState* __restrict__ state) {
+                                                  TgState* __restrict__ state, int only_redo) {
+  if (only_redo && state->redo == 0) return;
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
   const int64_t Fpad = n_slices * kSlice;
   uint32_t tiny = 0;
+  // An element the planes cannot hold at its feature's scale (twice the bound or more, or not
+  // finite; a nonzero one where the bound is zero).  With exact maxima only a non-finite element
+  // can be one; with a sample's (state->sampled) an outlier the sample missed is one too, and the
+  // operand then goes through the exact passes that stand behind this one.
+  bool beyond = false;
+  const uint32_t* bounds = bound_of(state, int(Fpad));
+  // (a zero bound travels as a negative scale: the element test needs to know, the product does not)
+  auto scale_of = [&](int64_t f) { return f < F ? (bounds[f] == 0 ? -1.0f : tg_scale(bounds[f])) : 1.0f; };
   // (one node per pass and set of threads: the 4-byte stores bound this kernel, more loads in
   // flight do not help; a node of one or two slices needs 64 or 128 threads, so the workgroup
   // takes blockDim / that many nodes side by side)
@@ -675,8 +691,8 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
 #pragma unroll
   for (int c = 0; c < kKeep; ++c) {
     const int64_t f = 2 * int64_t(tin) + 2 * int64_t(lanes_node) * c;
-    sc[c][0] = f < F ? tg_scale(state->amax[f]) : 1.0f;
-    sc[c][1] = f + 1 < F ? tg_scale(state->amax[f + 1]) : 1.0f;
+    sc[c][0] = scale_of(f);
+    sc[c][1] = scale_of(f + 1);
   }
   for (int64_t node = int64_t(blockIdx.x) * subs + sub; sub < subs && node < n; node += int64_t(gridDim.x) * subs) {
     const float sr = scale_row ? scale_row[node] : 1.0f;
@@ -692,8 +708,13 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
         if (f + 1 < F) x[1] = row[f + 1];
       }
       _Float16 hi[2], lo[2];
-      tg_split_one(x[0] * sr, s0, hi[0], lo[0], tiny);   // x * sr: the reference's scaling (utils.py:93), fp32
-      tg_split_one(x[1] * sr, s1, hi[1], lo[1], tiny);
+      const float x0 = x[0] * sr, x1 = x[1] * sr;        // x * sr: the reference's scaling (utils.py:93), fp32
+      const float a0 = s0 < 0.0f ? 1.0f : s0, a1 = s1 < 0.0f ? 1.0f : s1;
+      // (the scale puts the bound into [2^14, 2^15): below 2^15 an element is at most twice its bound and fp16 holds it)
+      beyond |= !(__builtin_fabsf(x0 * a0) < 32768.0f) || !(__builtin_fabsf(x1 * a1) < 32768.0f) ||
+                (s0 < 0.0f && x0 != 0.0f) || (s1 < 0.0f && x1 != 0.0f);
+      tg_split_one(x0, a0, hi[0], lo[0], tiny);
+      tg_split_one(x1, a1, hi[1], lo[1], tiny);
       const int64_t slice = f / kSlice;
       const int within = int(f % kSlice);
       char* dst = planes + slice * slice_stride + node * kRowBytes + within * 2;
@@ -709,12 +730,19 @@ __global__ __launch_bounds__(1024) void k_tg_split(int64_t n, int64_t F, int64_t
       f += 2 * int64_t(lanes_node);
     }
     for (; f < Fpad; f += 2 * int64_t(lanes_node))
-      body(f, f < F ? tg_scale(state->amax[f]) : 1.0f, f + 1 < F ? tg_scale(state->amax[f + 1]) : 1.0f);
+      body(f, scale_of(f), scale_of(f + 1));
   }
   // one atomic per wavefront
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) tiny += uint32_t(__shfl_xor(int(tiny), off));
-  if ((threadIdx.x & (kWave - 1)) == 0 && tiny) atomicAdd(&state->tiny, tiny);
+  const bool any_beyond = __any(beyond);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    if (tiny) atomicAdd(&state->tiny, tiny);
+    if (any_beyond) {
+      if (state->sampled) atomicOr(&state->redo, 1u);
+      else atomicOr(&state->flag, 1u);
+    }
+  }
 }
 
 // A continuous distribution leaves tiny elements where values cross zero: about one in 10^7 of
@@ -729,12 +757,25 @@ __host__ __device__ inline uint32_t tg_tiny_limit(int64_t elements) {
 }
 
 // an operand split from fp32: its scales derive from its own measured maxima
-__global__ void k_tg_state_init(TgState* __restrict__ state, uint32_t tiny_limit, int Fpad) {
+// (margin > 0: the maxima are a sample's; the bound is 2^margin times the sampled maximum, and an
+// element beyond twice that sends the operand through the exact passes -- see sgnn_tilegroup_split_f32)
+__global__ void k_tg_state_init(TgState* __restrict__ state, uint32_t tiny_limit, int Fpad, int margin, int only_redo) {
+  if (only_redo && state->redo == 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) state->tiny_limit = tiny_limit;
+  if (i == 0) {
+    state->tiny_limit = tiny_limit;
+    state->sampled = margin > 0 ? 1u : 0u;
+    if (only_redo) state->tiny = 0;   // counted against the provisional scales
+  }
   if (i < Fpad) {
-    bound_of(state, Fpad)[i] = state->amax[i];
-    if (state->amax[i] >= 0x7F800000u) atomicOr(&state->flag, 1u);   // a non-finite element
+    const uint32_t m = state->amax[i];
+    uint32_t b = m;
+    if (margin > 0 && m != 0 && m < 0x7F800000u) {
+      b = m + (uint32_t(margin) << 23);
+      if (b >= 0x7F800000u) b = 0x7F7FFFFFu;
+    }
+    bound_of(state, Fpad)[i] = b;
+    if (m >= 0x7F800000u) atomicOr(&state->flag, 1u);   // a non-finite element
   }
 }
 
@@ -1241,7 +1282,7 @@ __device__ __forceinline__ void tg_run(TgKernArgs& a, const int item, const int 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const uint32_t bnd = a.bound_in[f0 + i];
-    const uint32_t nxt = (to_planes && a.adapt) ? a.amax_in[f0 + i] : bnd;
+    const uint32_t nxt = (to_planes && a.adapt && !a.state->sampled) ? a.amax_in[f0 + i] : bnd;
     const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
     inv4[i] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);   // 1 / scale, exact: a power of two
     sc4[i] = tg_scale(nxt);
@@ -1480,7 +1521,7 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     for (int sl = blockIdx.x; sl < a.slices; sl += gridDim.x)
       if (threadIdx.x < kSlice) {
         const int f = sl * kSlice + threadIdx.x;
-        a.bound_out[f] = a.adapt ? a.amax_in[f] : a.bound_in[f];
+        a.bound_out[f] = (a.adapt && !a.state->sampled) ? a.amax_in[f] : a.bound_in[f];
       }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.state_out->tiny_limit = a.tiny_limit_out;
   }
@@ -1596,7 +1637,7 @@ __global__ __launch_bounds__(1024) void k_tg_combine(TgArgs a) {
       for (int j = 0; j < 4; ++j) {
         const int f = f4 + j;
         const uint32_t bnd = f < a.F ? a.bound_in[f] : 0u;
-        nb[j] = (to_planes && a.adapt && f < a.F) ? a.amax_in[f] : bnd;
+        nb[j] = (to_planes && a.adapt && !a.state->sampled && f < a.F) ? a.amax_in[f] : bnd;
         const uint32_t sb = __builtin_bit_cast(uint32_t, tg_scale(bnd));
         inv_in[j] = __builtin_bit_cast(float, (254u - (sb >> 23)) << 23);
       }
@@ -1705,6 +1746,7 @@ void set_tilegroup_mode(int m) { g_tg_mode = m; }
 void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 0; }
 void set_tilegroup_order(int cols) { g_order_cols = cols; }
 void set_tilegroup_combine_rows(int gy) { g_combine_gy = gy; }
+void set_tilegroup_no_sample(int v) { g_no_sample = v; }
 }  // namespace sgnn
 
 extern "C" {
@@ -1873,6 +1915,40 @@ size_t sgnn_tilegroup_state_bytes(int64_t F) {
   return align_up(tg_state_live_bytes(Fpad) + size_t(kAmaxBlocks) * Fpad * sizeof(uint32_t));
 }
 
+namespace {
+// per-feature maxima of every rstep-th row (rstep = 1: all of them) into state->amax
+int tg_amax_launch(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, TgState* s, int64_t rstep,
+                   int only_redo, hipStream_t st) {
+  const int Fpad = int((F + kSlice - 1) / kSlice * kSlice);
+  const int64_t rows = (n + rstep - 1) / rstep;
+  const int64_t per_row = (F + 1) / 2;
+  const unsigned T = unsigned(per_row >= 1024 ? 1024 : (per_row <= 256 ? 256 : (per_row + kWave - 1) / kWave * kWave));
+  // two workgroups per CU, each with many rows; their maxima meet in the fold kernel
+  const int64_t quads = (rows + 3) / 4;
+  const int blocks = int(quads < kAmaxBlocks ? quads : kAmaxBlocks);
+  hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(blocks)), dim3(T), 0, st, rows, F, Fpad, scale_row, X, ldx, s, rstep, only_redo);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tg_amax_fold, dim3(unsigned((F + 63) / 64)), dim3(1024), 0, st, int(F), Fpad, blocks, s, only_redo);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+
+// bounds from the maxima (times 2^margin), then the planes
+int tg_planes_launch(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* planes,
+                     int64_t plane_rows, int64_t operand_rows, TgState* s, int margin, int only_redo, hipStream_t st) {
+  const int64_t slices = (F + kSlice - 1) / kSlice;
+  const int Fpad = int(slices * kSlice);
+  hipLaunchKernelGGL(k_tg_state_init, dim3(unsigned((Fpad + 255) / 256)), dim3(256), 0, st, s,
+                     tg_tiny_limit(operand_rows * F), Fpad, margin, only_redo);
+  HIP_TRY(hipGetLastError());
+  const unsigned row_blocks = unsigned(n < 16384 ? n : 16384);
+  hipLaunchKernelGGL(k_tg_split, dim3(row_blocks), dim3(256), 0, st, n, F, slices, scale_row, X, ldx,
+                     static_cast<char*>(planes), plane_rows * int64_t(kRowBytes), s, only_redo);
+  HIP_TRY(hipGetLastError());
+  return SGNN_OK;
+}
+}  // namespace
+
 int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* state,
                             void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1882,16 +1958,7 @@ int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const 
   TgState* s = static_cast<TgState*>(state);
   const int Fpad = int((F + kSlice - 1) / kSlice * kSlice);
   HIP_TRY(hipMemsetAsync(s, 0, tg_state_live_bytes(Fpad), st));
-  const int64_t per_row = (F + 1) / 2;
-  const unsigned T = unsigned(per_row >= 1024 ? 1024 : (per_row <= 256 ? 256 : (per_row + kWave - 1) / kWave * kWave));
-  // two workgroups per CU, each with many rows; their maxima meet in the fold kernel
-  const int64_t quads = (n + 3) / 4;
-  const int blocks = int(quads < kAmaxBlocks ? quads : kAmaxBlocks);
-  hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(blocks)), dim3(T), 0, st, n, F, Fpad, scale_row, X, ldx, s);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_tg_amax_fold, dim3(unsigned((F + 63) / 64)), dim3(1024), 0, st, int(F), Fpad, blocks, s);
-  HIP_TRY(hipGetLastError());
-  return SGNN_OK;
+  return tg_amax_launch(n, F, scale_row, X, ldx, s, 1, 0, st);
 }
 
 int sgnn_tilegroup_planes_f32(int64_t n, int64_t F, const float* scale_row, const float* X, int64_t ldx, void* planes,
@@ -1902,26 +1969,46 @@ int sgnn_tilegroup_planes_f32(int64_t n, int64_t F, const float* scale_row, cons
   if (ldx < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
   if (plane_rows < n || operand_rows < n) return fail(SGNN_ERR_INVALID, "the planes hold fewer rows than are written");
   if (reinterpret_cast<uintptr_t>(planes) % 16) return fail(SGNN_ERR_INVALID, "planes must be 16-byte aligned");
-  const int64_t slices = (F + kSlice - 1) / kSlice;
-  TgState* s = static_cast<TgState*>(state);
-  const int Fpad = int(slices * kSlice);
-  hipLaunchKernelGGL(k_tg_state_init, dim3(unsigned((Fpad + 255) / 256)), dim3(256), 0, st, s,
-                     tg_tiny_limit(operand_rows * F), Fpad);
-  HIP_TRY(hipGetLastError());
-  const unsigned row_blocks = unsigned(n < 16384 ? n : 16384);
-  hipLaunchKernelGGL(k_tg_split, dim3(row_blocks), dim3(256), 0, st, n, F, slices, scale_row, X, ldx,
-                     static_cast<char*>(planes), plane_rows * int64_t(kRowBytes), s);
-  HIP_TRY(hipGetLastError());
-  return SGNN_OK;
+  return tg_planes_launch(n, F, scale_row, X, ldx, planes, plane_rows, operand_rows, static_cast<TgState*>(state), 0, 0, st);
 }
+
+// Operands of kSampleMinRows rows and more are split at PROVISIONAL scales: the per-feature
+// maxima of every kSampleStep-th row, times 2^kSampleMargin, stand in for the maxima of all rows,
+// which saves the pass that reads the whole operand once just to find them (a third of the
+// max + split time; 8 % of a hop on R-MAT 10 M, 6 % on ogbn-products, 3 % on the Reddit
+// shape).  The split pass tests every element against its feature's bound anyway; one beyond it
+// (an outlier the sample missed: more than 2^kSampleMargin times the sampled maximum) raises
+// `redo` in the state, and the exact passes -- maxima of all rows, bounds without margin, the
+// split again -- which are launched behind the provisional ones in any case, then run instead of
+// returning at once.  No host synchronisation either way.  What the margin costs: up to
+// kSampleMargin of the 29 bits of headroom below the bound in which an element keeps 22 bits.
+constexpr int64_t kSampleMinRows = 65536, kSampleStep = 32;
+constexpr int kSampleMargin = 3;
 
 int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, const float* X, int64_t ldx,
                              void* planes, size_t planes_bytes, void* state, void* stream) {
   if (n_cols <= 0 || F <= 0) return fail(SGNN_ERR_INVALID, "empty operand");
   if (planes_bytes < sgnn_tilegroup_planes_bytes(n_cols, F)) return fail(SGNN_ERR_WORKSPACE, "planes buffer too small");
-  int rc = sgnn_tilegroup_amax_f32(n_cols, F, scale_row, X, ldx, state, stream);
+  if (n_cols < kSampleMinRows || g_no_sample.load()) {
+    int rc = sgnn_tilegroup_amax_f32(n_cols, F, scale_row, X, ldx, state, stream);
+    if (rc != SGNN_OK) return rc;
+    return sgnn_tilegroup_planes_f32(n_cols, F, scale_row, X, ldx, planes, n_cols, n_cols, state, stream);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!X || !planes || !state) return fail(SGNN_ERR_INVALID, "null pointer");
+  if (ldx < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
+  if (reinterpret_cast<uintptr_t>(planes) % 16) return fail(SGNN_ERR_INVALID, "planes must be 16-byte aligned");
+  TgState* s = static_cast<TgState*>(state);
+  const int Fpad = int((F + kSlice - 1) / kSlice * kSlice);
+  HIP_TRY(hipMemsetAsync(s, 0, tg_state_live_bytes(Fpad), st));
+  int rc = tg_amax_launch(n_cols, F, scale_row, X, ldx, s, kSampleStep, 0, st);
   if (rc != SGNN_OK) return rc;
-  return sgnn_tilegroup_planes_f32(n_cols, F, scale_row, X, ldx, planes, n_cols, n_cols, state, stream);
+  rc = tg_planes_launch(n_cols, F, scale_row, X, ldx, planes, n_cols, n_cols, s, kSampleMargin, 0, st);
+  if (rc != SGNN_OK) return rc;
+  // the exact passes, which do nothing unless the provisional split raised `redo`
+  rc = tg_amax_launch(n_cols, F, scale_row, X, ldx, s, 1, 1, st);
+  if (rc != SGNN_OK) return rc;
+  return tg_planes_launch(n_cols, F, scale_row, X, ldx, planes, n_cols, n_cols, s, 0, 1, st);
 }
 
 size_t sgnn_spmm_tilegroup_workspace_bytes(int64_t partial_slots, int64_t F) {

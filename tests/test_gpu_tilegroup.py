@@ -344,3 +344,67 @@ def test_slice_ranges_equal_the_whole_launch_bit_for_bit(gpu_device, weight, to_
             _lib.ptr(state), _lib.ptr(whole if not to_planes else torch.zeros(n, F, device=gpu_device)), F, _lib.EPI_SCALE_ROW,
             _lib.ptr(ws), ws.numel(), adj.nnz, None, None, None, None, None, 0, None, 0, 0, None, 0, None, 0, 0, None, 1,
             4, 2, 0, st))
+
+
+def test_provisional_scales_from_a_sample_and_the_exact_passes_behind_them(gpu_device):
+    """Operands of 65536 rows and more are split at scales taken from every 32nd row (times 8).
+    Ordinary data: the exact passes behind the split do nothing (redo word 0) and the result
+    meets the same bound.  An outlier the sample missed, a column that is zero in every sampled
+    row, a value between the provisional bound and twice it: the exact passes run (redo word 1)
+    and the result is bit for bit the one of a library told never to sample.  A non-finite
+    element in an unsampled row still ends in the plain kernel's result."""
+    from sgnn_amd import _lib
+    lib = _lib.load()
+    n, F = 100_000, 96
+    adj, r, c, v = _graph(n, 1_500_000, seed=31, dev=gpu_device)
+    g = torch.Generator(device=gpu_device); g.manual_seed(7)
+    X = torch.randn(n, F, device=gpu_device, generator=g)
+
+    def run(Xd, order=2):
+        Y = adj.propagate(Xd, order)
+        torch.cuda.synchronize()
+        st = adj._tg_bufs[F]["states"]
+        return Y, [int(x) for x in st[0, :8].tolist()], int(adj._tg_bufs[F]["state"][_lib.TG_STATE_FLAG].item())
+
+    adj.use_tilegroup = False
+    ref = adj.propagate(X, 2)
+    scale = adj.propagate(adj.propagate(X.abs(), 1), 1)
+    adj.use_tilegroup = True
+    Y, head, flag = run(X)
+    assert adj._tg, "tile-group plan was not built"
+    assert flag == 0 and head[2] == 0 and head[3] == 1          # words 2, 3: redo, sampled
+    assert float(((Y - ref).abs() / scale.clamp_min(1e-30)).max()) <= 2.0 ** -19
+    lib.sgnn_tune_set(b"tg_no_sample", 1)
+    try:
+        Ye, head_e, _ = run(X)
+        assert head_e[2] == 0 and head_e[3] == 0
+        assert float(((Ye - ref).abs() / scale.clamp_min(1e-30)).max()) <= 2.0 ** -19
+        for what in ("outlier", "zero column", "just beyond"):
+            Xo = X.clone()
+            if what == "outlier":
+                Xo[7, 3] = 5000.0                                   # row 7 is not sampled (rows 0, 32, 64, ...)
+            elif what == "zero column":
+                Xo[:, 5] = 0.0
+                Xo[33, 5] = 1.0
+            else:
+                col = Xo[:, 9]
+                col[1::32] = 0.0                                    # keep the sampled maximum where it is ...
+                sampled_max = float((Xo[::32, 9] * adj.dinv[::32]).abs().max())
+                Xo[1, 9] = 40.0 * sampled_max / float(adj.dinv[1])  # ... and put 40 x that (bound: 8 x, up to 16 x passes) in an unsampled row
+            lib.sgnn_tune_set(b"tg_no_sample", 1)
+            Y_exact, _, f1 = run(Xo)
+            lib.sgnn_tune_set(b"tg_no_sample", 0)
+            Y_redo, head_r, f2 = run(Xo)
+            assert f1 == 0 and f2 == 0, what
+            assert head_r[2] == 1 and head_r[3] == 0, (what, head_r)      # the exact passes ran and left exact maxima
+            assert torch.equal(Y_exact, Y_redo), what
+        Xi = X.clone()
+        Xi[12345, 17] = float("inf")
+        lib.sgnn_tune_set(b"tg_no_sample", 0)
+        Yi, _, fi = run(Xi, order=1)
+        assert fi != 0
+        adj.use_tilegroup, adj.use_rowgroup = False, False
+        Yp = adj.propagate(Xi, 1)
+        assert torch.equal(torch.nan_to_num(Yi, nan=1.5, posinf=2.5, neginf=-2.5), torch.nan_to_num(Yp, nan=1.5, posinf=2.5, neginf=-2.5))
+    finally:
+        lib.sgnn_tune_set(b"tg_no_sample", 0)

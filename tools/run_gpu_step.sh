@@ -1,3 +1,3 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -u tools/combine_probe.py 0,8,16,32,64,128,0,16,32 2>&1 | grep -v amdgpu.ids
+timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r03_full_tests.log 2>&1; echo rc=$?; tail -n 3 gpurun_out/r03_full_tests.log
