@@ -66,8 +66,9 @@ def kernel_of(adj, F):
     if adj._tilegroup_plan(F):
         return ("tile-group SpMM (512-row groups share fetched rows through LDS; fp16 hi/lo planes of X, one scale per "
                 "feature column, on v_mfma_f32_32x32x16_f16, fp32 accumulation)",
-                "k_tg_amax + k_tg_state_init + k_tg_split (first hop only; later hops of a chain read the planes the "
-                "epilogue before them wrote) + k_tg_spmm + k_tg_combine + guarded plain-CSR fall-back (returns at once)",
+                "k_tg_amax over every 32nd row + k_tg_state_init + k_tg_split + the exact max / split passes behind them "
+                "(return at once unless the sample missed an outlier) (first hop only; later hops of a chain read the planes "
+                "the epilogue before them wrote) + k_tg_spmm + k_tg_combine + guarded plain-CSR fall-back (returns at once)",
                 "k_tg_spmm")
     R = lib.sgnn_rowgroup_config_for(adj.n, adj.nnz, F) if adj.use_rowgroup else 0
     if R:
@@ -741,7 +742,7 @@ def main():
                          f"feature split: whole graph on each of {world} GPUs, {extra['features_per_rank']} columns each; "
                          "the caller's row blocks travel by all-to-all before the first and after the last hop"),
                 "arithmetic": "fp32 in, fp32 out, fp32 accumulation; the tile-group kernel feeds the matrix cores X as "
-                              "two fp16 planes (hi + lo/2048 at one power-of-two scale per feature column) that reproduce each fp32 "
+                              "two fp16 planes (hi + lo/2048 at one power-of-two scale per feature column, taken from a sample of the rows and checked element by element) that reproduce each fp32 "
                               "input to 2^-22 relative; operands they cannot represent take the plain fp32 kernel"
                               if main_kernel == "k_tg_spmm" else "fp32 throughout",
                 "graph_gen_s": round(t_gen, 2),

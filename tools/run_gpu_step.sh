@@ -1,3 +1,4 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r03_full_tests.log 2>&1; echo rc=$?; tail -n 3 gpurun_out/r03_full_tests.log
+timeout -k 10 900 python -u bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err || { tail -n 20 gpurun_out/r03_bench.err; exit 1; }
+echo bench done
