@@ -25,6 +25,8 @@ LOOPS_NONE, LOOPS_ADD, LOOPS_REMAINING = 0, 1, 2
 EPI_SCALE_ROW, EPI_SCALE_ROW2 = 0, 1
 # tile-group operand state (sgnn_tilegroup_state_bytes): 32-bit words; the per-feature maxima follow the header
 TG_STATE_FLAG, TG_STATE_TINY, TG_STATE_TINY_LIMIT, TG_STATE_HEAD_WORDS = 1, 4, 6, 16
+# words 2 and 3: the exact max / split passes ran behind a provisional split; the maxima are a sample's
+TG_STATE_REDO, TG_STATE_SAMPLED = 2, 3
 
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {

@@ -372,7 +372,7 @@ def test_provisional_scales_from_a_sample_and_the_exact_passes_behind_them(gpu_d
     adj.use_tilegroup = True
     Y, head, flag = run(X)
     assert adj._tg, "tile-group plan was not built"
-    assert flag == 0 and head[2] == 0 and head[3] == 1          # words 2, 3: redo, sampled
+    assert flag == 0 and head[_lib.TG_STATE_REDO] == 0 and head[_lib.TG_STATE_SAMPLED] == 1
     assert float(((Y - ref).abs() / scale.clamp_min(1e-30)).max()) <= 2.0 ** -19
     lib.sgnn_tune_set(b"tg_no_sample", 1)
     try:
