@@ -408,3 +408,47 @@ def test_provisional_scales_from_a_sample_and_the_exact_passes_behind_them(gpu_d
         assert torch.equal(torch.nan_to_num(Yi, nan=1.5, posinf=2.5, neginf=-2.5), torch.nan_to_num(Yp, nan=1.5, posinf=2.5, neginf=-2.5))
     finally:
         lib.sgnn_tune_set(b"tg_no_sample", 0)
+
+
+@pytest.mark.parametrize("F,order,weight,dist_kind", [(16, 2, None, "normal"), (41, 3, 2.0, "lognormal"), (130, 2, None, "lognormal"),
+                                                      (602, 1, 2.0, "normal"), (64, 2, None, "sparse")])
+def test_provisional_scales_across_widths_and_distributions(gpu_device, F, order, weight, dist_kind):
+    """Just above the sampling threshold (70 000 rows): Gaussian data keeps the provisional scales,
+    heavy-tailed (log-normal, sigma 3) and mostly-zero data send some operands through the exact
+    passes; either way the result meets the 1e-5 bound against the plain kernel, and where the
+    exact passes ran it is bit for bit the result of a library that never samples."""
+    from sgnn_amd import _lib
+    lib = _lib.load()
+    n = 70_000
+    adj, r, c, v = _graph(n, 900_000, seed=40 + F, dev=gpu_device, weight=weight)
+    g = torch.Generator(device=gpu_device); g.manual_seed(F)
+    X = torch.randn(n, F, device=gpu_device, generator=g)
+    if dist_kind == "lognormal":
+        X = torch.exp(3.0 * X) * torch.sign(torch.randn(n, F, device=gpu_device, generator=g))
+    elif dist_kind == "sparse":
+        X = X * (torch.rand(n, F, device=gpu_device, generator=g) < 0.002)
+    adj.use_tilegroup, adj.use_rowgroup = False, False
+    ref = adj.propagate(X, order)
+    scale = adj.propagate(X.abs(), order)
+    adj.use_tilegroup, adj.use_rowgroup = True, True
+    try:
+        lib.sgnn_tune_set(b"tg_no_sample", 0)
+        Y = adj.propagate(X, order)
+        torch.cuda.synchronize()
+        assert adj._tg, "tile-group plan was not built"
+        st = adj._tg_bufs[F]["states"]
+        flags = st[:order, _lib.TG_STATE_FLAG].tolist()
+        redo = int(st[0, _lib.TG_STATE_REDO].item())
+        if any(flags):      # a dynamic range the planes refuse (log-normal columns may): the plain kernel's result, bit for bit
+            assert torch.equal(Y, ref)
+        else:
+            assert float(((Y - ref).abs() / scale.clamp_min(1e-30)).max()) <= TOL
+            assert float((Y - ref).norm() / ref.norm()) <= TOL
+        if dist_kind == "normal":
+            assert redo == 0 and not any(flags)
+        lib.sgnn_tune_set(b"tg_no_sample", 1)
+        Ye = adj.propagate(X, order)
+        if redo:
+            assert torch.equal(Y, Ye)
+    finally:
+        lib.sgnn_tune_set(b"tg_no_sample", 0)
