@@ -1652,18 +1652,19 @@ __global__ __launch_bounds__(1024) void k_tg_combine(TgArgs a) {
                            : 0.0f;
       const float* pp = a.partial + (int64_t(slot) * kRows + rr) * a.Fpad + f4;
       f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-      int k = 0;
-      for (; k + 4 <= nseg; k += 4) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(pp + (k + 0) * stride);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(pp + (k + 1) * stride);
-        const f32x4 v2 = *reinterpret_cast<const f32x4*>(pp + (k + 2) * stride);
-        const f32x4 v3 = *reinterpret_cast<const f32x4*>(pp + (k + 3) * stride);
-        s += v0;
-        s += v1;
-        s += v2;
-        s += v3;
+      // four loads in flight whatever the number of pieces (most groups are cut in two to four): a
+      // piece that does not exist reads the last one again and adds zero, which changes no bit
+      // (the sum starts from +0, so its zeros are +0 already)
+      for (int k = 0; k < nseg; k += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(pp + (k + i < nseg ? k + i : nseg - 1) * stride);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (k + i >= nseg) v[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          s += v[i];
+        }
       }
-      for (; k < nseg; ++k) s += *reinterpret_cast<const f32x4*>(pp + k * stride);
       _Float16 hv[4], lv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

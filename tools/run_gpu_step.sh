@@ -1,3 +1,4 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python -u -m pytest tests/test_gpu_tilegroup.py -x -v --timeout 150 --timeout-method thread -k "provisional" > gpurun_out/t_pv.log 2>&1; echo rc=$?; grep -E "PASSED|FAILED|^E |passed|failed" gpurun_out/t_pv.log | head -n 24
+for v in ab_old.so sgnn_amd/libsgnn_hip.so ab_old.so sgnn_amd/libsgnn_hip.so; do timeout -k 10 200 python -u tools/ab_lib.py $v 2>&1 | grep -v amdgpu.ids | cut -c1-120 || exit 1; done
+timeout -k 10 500 python -u -m pytest tests/test_gpu_tilegroup.py -x -q --timeout 120 --timeout-method thread > gpurun_out/t_tg.log 2>&1; rc=$?; tail -n 2 gpurun_out/t_tg.log; [ $rc -eq 0 ] || { grep -E "^E |FAILED" gpurun_out/t_tg.log | head; exit 1; }
