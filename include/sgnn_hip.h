@@ -222,7 +222,7 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           counts; an SpMM launch whose counts differ raises the flag
  *                           (bit 4) instead of reading the plan with the wrong layout.
  * Per operand, `state` = sgnn_tilegroup_state_bytes(F) of device memory: the fall-back flag
- * (second 32-bit word; first word: bit pattern of the largest magnitude seen), the count of
+ * (second 32-bit word), the count of
  * tiny elements (fifth word), the work counter of the SpMM launch, and per feature the
  * measured largest magnitude and the bound its scale derives from:
  *   sgnn_tilegroup_amax_f32   clears `state` and measures max |scale_row[i] * X[i, f]| per feature
@@ -269,8 +269,9 @@ int sgnn_spmm_chain_f32(int K, int64_t n, int64_t nnz, int64_t F,
  *                           largest of x'; an operand that breaks the bound is caught by the
  *                           element check and refused.
  *                           The launch is one workgroup per CU; the workgroups take (work
- *                           item, feature slice) pairs off a counter kept in `state`, which
- *                           the call zeroes: two SpMM calls that share a `state` must not
+ *                           item, feature slice) pairs off a counter kept in `state` (zero
+ *                           when the state is made, zeroed again by the last workgroup of
+ *                           every launch): two SpMM calls that share a `state` must not
  *                           overlap (calls in one stream never do).
  *   sgnn_spmm_tilegroup_slices_f32  the same product for the operand's 128-feature slices
  *                           slice_begin .. slice_begin + slice_count - 1 only (slice_count <= 0:

@@ -92,14 +92,14 @@ std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_orde
 std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only (results are then wrong); 128 = one workgroup per unit, 256 / 1024 = one work counter per XCD / one for the launch whatever the plan says
 
 struct TgState {          // device words that carry an operand's scales and its fall-back flag to the SpMM that reads it
-  uint32_t amax_all;      // bit pattern of the largest |element| over all features (diagnostics)
+  uint32_t rsv0;
   uint32_t flag;          // != 0: the operand cannot go through the fp16 planes (1: an element, 2: too many tiny ones, 4: plan mismatch, 8: inherited from the hop before)
   uint32_t redo;          // the split pass met an element its sampled bound cannot hold: the exact passes behind it run
   uint32_t sampled;       // the maxima are those of a sample of the rows (the bounds carry a margin): not a bound for the next operand
   uint32_t tiny;          // nonzero elements that keep fewer than 17 of their bits in the planes
-  uint32_t rsv2;
+  uint32_t done;          // workgroups of the running SpMM launch that have left the work loop (the last one zeroes the work counters)
   uint32_t tiny_limit;    // more tiny elements than this: fall back
-  uint32_t queue;         // next work index of the running SpMM launch (this word and the eight behind it are zeroed by the SpMM call)
+  uint32_t queue;         // next work index of the running SpMM launch (this word and the eight behind it are zero between launches)
   uint32_t xcd_queue[8];  // the same, one per XCD (see k_tg_spmm)
   // [Fpad] per feature, the bit pattern of its largest |element| as measured while the operand
   // was written, followed by [Fpad] the bound its scale was derived from.  An operand split
@@ -531,13 +531,15 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, int Fpad
   // n rows, every rstep-th of the operand (a sample gives the split pass its provisional scales);
   // only_redo: the exact pass behind a split that met an element beyond them -- nothing to do otherwise
   if (only_redo && state->redo == 0) return;
+  // the first pass over an operand also clears the state's header (flag, counters, work counters:
+  // no other workgroup of this kernel touches it; the kernels behind it in the stream fill it in)
+  if (!only_redo && blockIdx.x == 0 && threadIdx.x < kStateHead / 4) reinterpret_cast<uint32_t*>(state)[threadIdx.x] = 0u;
   __shared__ uint32_t smax[2048];
   const bool pairs = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 8 == 0);
   const int V = pairs ? 2 : 1;
   const int per_row = int((F + V - 1) / V);
   const int lanes_row = per_row >= int(blockDim.x) ? int(blockDim.x) : (per_row + kWave - 1) / kWave * kWave;
   const int subs = int(blockDim.x) / lanes_row, sub = int(threadIdx.x) / lanes_row, tin = int(threadIdx.x) % lanes_row;
-  uint32_t all = 0;
   for (int64_t fbase = 0; fbase < F; fbase += int64_t(V) * lanes_row) {
     const int64_t f = fbase + int64_t(V) * tin;
     uint32_t m0 = 0, m1 = 0;
@@ -580,16 +582,8 @@ __global__ __launch_bounds__(1024) void k_tg_amax(int64_t n, int64_t F, int Fpad
       uint32_t* mine = scratch_of(state, Fpad) + int64_t(blockIdx.x) * Fpad;
       mine[f] = m0;
       if (V == 2 && f + 1 < F) mine[f + 1] = m1;
-      all = m0 > all ? m0 : all;
-      all = m1 > all ? m1 : all;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const uint32_t o = uint32_t(__shfl_xor(int(all), off));
-    all = o > all ? o : all;
-  }
-  if ((threadIdx.x & (kWave - 1)) == 0 && all) atomicMax(&state->amax_all, all);
 }
 
 // the workgroups' maxima folded per feature: a workgroup takes 64 features, its 16 wavefronts
@@ -622,10 +616,10 @@ __global__ __launch_bounds__(1024) void k_tg_amax_fold(int F, int Fpad, int bloc
   }
   part[by][fx] = m;
   __syncthreads();
-  if (by == 0 && f < F) {
+  if (by == 0 && f < Fpad) {   // (the padding features' maxima are zero: the kernels behind read them like any other)
 #pragma unroll
     for (int i = 1; i < 16; ++i) m = part[i][fx] > m ? part[i][fx] : m;
-    state->amax[f] = m;
+    state->amax[f] = f < F ? m : 0u;
   }
 }
 
@@ -1592,6 +1586,17 @@ __global__ __launch_bounds__(kWaves* kWave, 2) void k_tg_spmm(TgArgs a) {
     }
     if (a.mode & 128) break;   // diagnostics: one workgroup per (item, slice) pair
   }
+  // The last workgroup to get here zeroes the work counters for the next launch that uses this
+  // state (every workgroup is past its last ticket by then), which saves a memset per launch.
+  if (!(a.mode & 128) && threadIdx.x == 0) {
+    const uint32_t gone = atomicAdd(&a.state->done, 1u);
+    if (gone == gridDim.x - 1) {
+      a.state->queue = 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a.state->xcd_queue[q] = 0u;
+      a.state->done = 0u;
+    }
+  }
 }
 
 // rows of a group cut into several items: add the items' partial rows in order, then the row epilogue
@@ -1929,7 +1934,7 @@ int tg_amax_launch(int64_t n, int64_t F, const float* scale_row, const float* X,
   const int blocks = int(quads < kAmaxBlocks ? quads : kAmaxBlocks);
   hipLaunchKernelGGL(k_tg_amax, dim3(unsigned(blocks)), dim3(T), 0, st, rows, F, Fpad, scale_row, X, ldx, s, rstep, only_redo);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_tg_amax_fold, dim3(unsigned((F + 63) / 64)), dim3(1024), 0, st, int(F), Fpad, blocks, s, only_redo);
+  hipLaunchKernelGGL(k_tg_amax_fold, dim3(unsigned(Fpad / 64)), dim3(1024), 0, st, int(F), Fpad, blocks, s, only_redo);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;
 }
@@ -1958,7 +1963,6 @@ int sgnn_tilegroup_amax_f32(int64_t n, int64_t F, const float* scale_row, const 
   if (ldx < F) return fail(SGNN_ERR_INVALID, "leading dimension smaller than F");
   TgState* s = static_cast<TgState*>(state);
   const int Fpad = int((F + kSlice - 1) / kSlice * kSlice);
-  HIP_TRY(hipMemsetAsync(s, 0, tg_state_live_bytes(Fpad), st));
   return tg_amax_launch(n, F, scale_row, X, ldx, s, 1, 0, st);
 }
 
@@ -2001,7 +2005,6 @@ int sgnn_tilegroup_split_f32(int64_t n_cols, int64_t F, const float* scale_row, 
   if (reinterpret_cast<uintptr_t>(planes) % 16) return fail(SGNN_ERR_INVALID, "planes must be 16-byte aligned");
   TgState* s = static_cast<TgState*>(state);
   const int Fpad = int((F + kSlice - 1) / kSlice * kSlice);
-  HIP_TRY(hipMemsetAsync(s, 0, tg_state_live_bytes(Fpad), st));
   int rc = tg_amax_launch(n_cols, F, scale_row, X, ldx, s, kSampleStep, 0, st);
   if (rc != SGNN_OK) return rc;
   rc = tg_planes_launch(n_cols, F, scale_row, X, ldx, planes, n_cols, n_cols, s, kSampleMargin, 0, st);
@@ -2115,7 +2118,8 @@ int sgnn_spmm_tilegroup_slices_f32(int64_t n_rows, int64_t n_cols, int64_t F, co
   // (the next operand's state is cleared by the launch that covers the operand's first slice:
   // launches over ranges of slices go in ascending order on one stream)
   if (planes_out != nullptr && slice_begin == 0) HIP_TRY(hipMemsetAsync(state_out, 0, tg_state_live_bytes(Fpad_all), st));
-  HIP_TRY(hipMemsetAsync(a.queue, 0, 9 * sizeof(uint32_t), st));   // the work counters: one for the launch, one per XCD
+  // (the work counters -- one for the launch, one per XCD -- are zero between launches: the state
+  // starts cleared and the last workgroup to leave a launch's work loop zeroes them again)
   // one workgroup per CU (a workgroup takes the whole LDS of one), fewer when there is less work
   sgnn::kernel_timer_begin(st);
   // (reserve_cus: CUs left to kernels of other streams -- a collective that runs beside this
