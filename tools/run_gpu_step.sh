@@ -1,4 +1,12 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -u -m pytest tests/test_gpu_tilegroup.py tests/test_gpu_planes_bound.py tests/test_gpu_dist.py tests/test_gpu_fullsize.py -x -q --timeout 200 --timeout-method thread > gpurun_out/t_tg.log 2>&1; rc=$?; tail -n 2 gpurun_out/t_tg.log; [ $rc -eq 0 ] || { grep -E "^E |FAILED" gpurun_out/t_tg.log | head; exit 1; }
-for v in ab_old.so sgnn_amd/libsgnn_hip.so ab_old.so sgnn_amd/libsgnn_hip.so; do timeout -k 10 200 python -u tools/ab_lib.py $v 2>&1 | grep -v amdgpu.ids | cut -c1-70 || exit 1; done
+run() { tag=$1; shift; bash tools/profile_gpu.sh $tag k_tg_spmm "$@" > gpurun_out/p_$tag.log 2>&1 || { tail -n 20 gpurun_out/p_$tag.log; exit 1; }; echo "$tag done"; }
+run r03_reddit_f602_tilegroup
+run r03_reddit_w2_tilegroup --weight 2
+run r03_reddit_clip22000_tilegroup --max-degree 22000
+run r03_reddit_order2_tilegroup --order 2
+run r03_reddit128_tilegroup --workload reddit128
+run r03_products_tilegroup --workload products
+run r03_rmat10m_tilegroup --workload rmat10m
+timeout -k 10 900 python -u bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err || { tail -n 20 gpurun_out/r03_bench.err; exit 1; }
+echo bench done
