@@ -34,6 +34,7 @@ void set_tilegroup_mode(int mode);        // diagnostic switches of the tile-gro
 void set_tilegroup_segment(int stages);   // stages per tile-group work item for plans built afterwards
 void set_tilegroup_combine_rows(int gy);  // workgroups per split group of the tile-group combine pass (0 = built-in)
 void set_tilegroup_no_sample(int v);      // 1: the tile-group split pass measures the maxima of all rows (no provisional scales)
+void set_tilegroup_split_shape(int blocks, int threads);   // launch shape of the tile-group split pass (-1: leave, 0: built-in)
 void set_tilegroup_order(int cols);       // tile-group items by column blocks of this width (0 = longest first)
 
 // sgnn_spmm_csr_f32 whose kernels do nothing while the device word *guard is 0 (guard may

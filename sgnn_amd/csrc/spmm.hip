@@ -598,6 +598,8 @@ int sgnn_tune_set(const char* key, int value) {
   else if (!std::strcmp(key, "tg_order")) sgnn::set_tilegroup_order(value);
   else if (!std::strcmp(key, "tg_combine_gy")) sgnn::set_tilegroup_combine_rows(value);
   else if (!std::strcmp(key, "tg_no_sample")) sgnn::set_tilegroup_no_sample(value);
+  else if (!std::strcmp(key, "tg_split_blocks")) sgnn::set_tilegroup_split_shape(value, -1);
+  else if (!std::strcmp(key, "tg_split_threads")) sgnn::set_tilegroup_split_shape(-1, value);
   else if (!std::strcmp(key, "time_kernel")) {
     std::lock_guard<std::mutex> lock(sgnn::g_timer_mu);
     sgnn::g_timer_on = value != 0;

@@ -87,6 +87,7 @@ static_assert(kTableBytes + kWaves * (kStageOutBytes + kRowTabBytes) <= kLdsByte
 
 std::atomic<int> g_seg_stages{0};     // stages per work item, longer merged lists are cut; 0: chosen from the plan's size (sgnn_tune_set("tg_seg", v))
 std::atomic<int> g_no_sample{0};      // sgnn_tune_set("tg_no_sample", 1): the split pass always measures the maxima of all rows first
+std::atomic<int> g_split_blocks{0}, g_split_threads{0};   // launch shape of the split pass (sgnn_tune_set("tg_split_blocks" / "tg_split_threads", v)); 0 = built-in
 std::atomic<int> g_combine_gy{0};     // workgroups per split group of the combine pass (sgnn_tune_set("tg_combine_gy", v)); 0 = the built-in choice
 std::atomic<int> g_order_cols{0};     // work item order (sgnn_tune_set("tg_order", v)): 0 = chosen by the graph; 1 = longest first; < 0 = neighbours together (length buckets, then column block, then group); > 1 = by column blocks of this width
 std::atomic<int> g_tg_mode{0};         // diagnostics (sgnn_tune_set("tg_mode", m)): 1 = no multiplication, 2 = no row DMA, 32 = no rows written, 64 = rows fetched from the first 4096 nodes only (results are then wrong); 128 = one workgroup per unit, 256 / 1024 = one work counter per XCD / one for the launch whatever the plan says
@@ -1753,6 +1754,10 @@ void set_tilegroup_segment(int stages) { g_seg_stages = stages >= 8 ? stages : 0
 void set_tilegroup_order(int cols) { g_order_cols = cols; }
 void set_tilegroup_combine_rows(int gy) { g_combine_gy = gy; }
 void set_tilegroup_no_sample(int v) { g_no_sample = v; }
+void set_tilegroup_split_shape(int blocks, int threads) {
+  if (blocks >= 0) g_split_blocks = blocks;
+  if (threads >= 0) g_split_threads = threads;
+}
 }  // namespace sgnn
 
 extern "C" {
@@ -1947,8 +1952,13 @@ int tg_planes_launch(int64_t n, int64_t F, const float* scale_row, const float* 
   hipLaunchKernelGGL(k_tg_state_init, dim3(unsigned((Fpad + 255) / 256)), dim3(256), 0, st, s,
                      tg_tiny_limit(operand_rows * F), Fpad, margin, only_redo);
   HIP_TRY(hipGetLastError());
-  const unsigned row_blocks = unsigned(n < 16384 ? n : 16384);
-  hipLaunchKernelGGL(k_tg_split, dim3(row_blocks), dim3(256), 0, st, n, F, slices, scale_row, X, ldx,
+  // Narrow operands have little work per row: fewer, longer-lived workgroups measure faster there
+  // (Reddit rows, 128 features: 0.073 -> 0.059 ms for max + split); wide operands and those with
+  // millions of rows prefer more of them (10 M rows of 128: 2.09 ms with 16384, 2.30 ms with 4096).
+  const int64_t max_blocks = g_split_blocks.load() > 0 ? g_split_blocks.load() : (F <= 128 ? std::min<int64_t>(16384, std::max<int64_t>(4096, n / 64)) : 16384);
+  const unsigned row_blocks = unsigned(n < max_blocks ? n : max_blocks);
+  const unsigned split_threads = unsigned(g_split_threads.load() > 0 ? g_split_threads.load() : 256);
+  hipLaunchKernelGGL(k_tg_split, dim3(row_blocks), dim3(split_threads), 0, st, n, F, slices, scale_row, X, ldx,
                      static_cast<char*>(planes), plane_rows * int64_t(kRowBytes), s, only_redo);
   HIP_TRY(hipGetLastError());
   return SGNN_OK;

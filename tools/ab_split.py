@@ -12,7 +12,12 @@ _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from sgnn_amd import _lib  # noqa: E402
 _lib.LIB_PATH = os.path.join(_root, sys.argv[1])
 lib = _lib.load()
+if os.environ.get("SPLIT_BLOCKS"):
+    lib.sgnn_tune_set(b"tg_split_blocks", int(os.environ["SPLIT_BLOCKS"]))
+if os.environ.get("SPLIT_THREADS"):
+    lib.sgnn_tune_set(b"tg_split_threads", int(os.environ["SPLIT_THREADS"]))
 dev = torch.device("cuda:0")
+torch.manual_seed(0)
 st = _lib.current_stream(dev)
 for name, n, F in (("reddit", 232965, 602), ("reddit128", 232965, 128), ("products", 2449029, 100), ("rmat10m", 10_000_000, 128),
                    ("reddit41", 232965, 41)):
@@ -32,6 +37,6 @@ for name, n, F in (("reddit", 232965, 602), ("reddit128", 232965, 128), ("produc
     e1.record()
     torch.cuda.synchronize()
     chk = int(planes.view(torch.int32)[: pb // 4].to(torch.int64).sum().item())
-    print(f"{sys.argv[1]} {name}: max + split {e0.elapsed_time(e1) / 20:.3f} ms, checksum of the planes {chk}, "
+    print(f"{sys.argv[1]} blocks={os.environ.get('SPLIT_BLOCKS', '-')} threads={os.environ.get('SPLIT_THREADS', '-')} {name}: max + split {e0.elapsed_time(e1) / 20:.3f} ms, checksum of the planes {chk}, "
           f"tiny {int(state[_lib.TG_STATE_TINY].item())} flag {int(state[_lib.TG_STATE_FLAG].item())}", flush=True)
     del X, planes

@@ -1,12 +1,5 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-run() { tag=$1; shift; bash tools/profile_gpu.sh $tag k_tg_spmm "$@" > gpurun_out/p_$tag.log 2>&1 || { tail -n 20 gpurun_out/p_$tag.log; exit 1; }; echo "$tag done"; }
-run r03_reddit_f602_tilegroup
-run r03_reddit_w2_tilegroup --weight 2
-run r03_reddit_clip22000_tilegroup --max-degree 22000
-run r03_reddit_order2_tilegroup --order 2
-run r03_reddit128_tilegroup --workload reddit128
-run r03_products_tilegroup --workload products
-run r03_rmat10m_tilegroup --workload rmat10m
-timeout -k 10 900 python -u bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err || { tail -n 20 gpurun_out/r03_bench.err; exit 1; }
-echo bench done
+timeout -k 10 200 python -u tools/ab_split.py sgnn_amd/libsgnn_hip.so > gpurun_out/split_final.log 2>&1 || exit 1
+timeout -k 10 600 python -u -m pytest tests/test_gpu_tilegroup.py tests/test_gpu_planes_bound.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r03_tg_tests.log 2>&1 || { tail -n 30 gpurun_out/r03_tg_tests.log; exit 1; }
+tail -n 3 gpurun_out/r03_tg_tests.log
