@@ -62,6 +62,8 @@ int sgnn_version(void);
  * tile-group work item, "tg_order" = order of the tile-group work items (0: chosen by the
  * graph, the default; 1: longest first; -1: neighbours together; > 1: by column blocks of
  * this width), "tg_combine_gy" = workgroups per split group of the tile-group combine pass,
+ * "tg_split_blocks" / "tg_split_threads" = launch shape of the tile-group split pass,
+ * "tg_no_sample" = 1 takes the per-feature maxima from every row instead of a sample first,
  * "tg_mode" = diagnostic switches of the tile-group kernel,
  * "time_kernel" = 1/0 turns the kernel timer on/off (see sgnn_kernel_time_ms); value 0
  * restores the built-in policy.  No reference counterpart. */
