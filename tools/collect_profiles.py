@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEP_KERNELS = ("k_tg_amax(", "k_tg_amax_fold", "k_tg_state_init", "k_tg_split", "k_tg_spmm", "k_tg_combine",
-                "k_rg_spmm", "k_rg_combine", "k_row_scale", "k_spmm<", "k_spmm_combine", "fillBufferAligned")
+                "k_rg_spmm", "k_rg_combine", "k_row_scale", "k_spmm<", "k_spmm_combine", "k_collect_long", "fillBufferAligned")
 
 
 def main():
@@ -41,9 +41,14 @@ def main():
             if hit is None:
                 continue
             label = {"k_tg_amax(": "k_tg_amax", "k_spmm<": "k_spmm (guarded fall-back)",
-                     "k_spmm_combine": "k_spmm_combine (guarded fall-back)", "fillBufferAligned": "memset"}.get(hit, hit)
+                     "k_spmm_combine": "k_spmm_combine (guarded fall-back)", "k_collect_long": "k_collect_long (guarded fall-back)", "fillBufferAligned": "memset"}.get(hit, hit)
             calls, avg = int(r["Calls"]), float(r["AverageNs"]) / 1e6
             if calls < steps:        # not part of every step (plan construction shares some names)
+                continue
+            if label == "memset":    # the trace cannot tell a step's fills from those of graph and plan construction
+                c[label] = {"avg_ms": round(avg, 5), "launches_in_traced_run": calls,
+                            "note": "graph and plan construction included; a one-hop step issues one fill "
+                                    "(the work counters of the guarded fall-back), a chain one more per hop"}
                 continue
             c[label] = {"avg_ms": round(avg, 5), "launches_per_step": round(calls / steps, 2)}
         c["source"] = f"profiles/{tag}_kernel_stats.csv ({steps} traced steps, warm-up included)"
