@@ -402,8 +402,9 @@ def main():
                     help="N > 1: also let the feature-sliced exchange/SpMM pipeline (fp32 rows, one block) of this many "
                          "slices compete with the default schedule (own-columns block multiplied while the exchange "
                          "runs); 1 = default schedule only")
-    ap.add_argument("--feature-groups", type=int, default=0,
-                    help="N > 1: extra grids to probe beside the row partition: 0 = every divisor of N, 1 = none, "
+    ap.add_argument("--feature-groups", type=int, default=1,
+                    help="N > 1: extra grids to probe beside the row partition: 1 = none (every collective of the run "
+                         "then uses the job's own process group), 0 = every divisor of N, "
                          "k = only k feature groups")
     ap.add_argument("--exchange", default="auto", choices=["allgather", "referenced", "auto"],
                     help="N > 1: rows of X a rank receives per hop: all of them (one all-gather), only the ones its "
